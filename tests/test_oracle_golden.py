@@ -1,0 +1,163 @@
+"""Pin the CPU oracle (oracle/llava_oracle.py) against outputs of the reference itself
+(tests/golden/*.npz, produced by tests/golden/make_golden.py in the build container)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import llava_oracle as O
+from radvlm_amd.config import GEOMETRIES
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _maxrel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def test_rmsnorm_rope_mlp(golden_dir):
+    g = _load(golden_dir, "per_op.npz")
+    x = torch.from_numpy(g["rms_x"]).requires_grad_(True)
+    w = torch.from_numpy(g["rms_w"]).requires_grad_(True)
+    y = O.rmsnorm(x, w)
+    y.backward(torch.from_numpy(g["rms_gy"]))
+    assert _maxrel(y.detach(), g["rms_y"]) < 1e-6
+    assert _maxrel(x.grad, g["rms_gx"]) < 1e-5
+    assert _maxrel(w.grad, g["rms_gw"]) < 1e-5
+    q, k = torch.from_numpy(g["rope_q"]), torch.from_numpy(g["rope_k"])
+    cos, sin = O.rope_cos_sin(q.shape[2], q.shape[3])
+    assert _maxrel(cos, g["rope_cos"][0]) < 1e-6 and _maxrel(sin, g["rope_sin"][0]) < 1e-6
+    qe, ke = O.apply_rope(q, k, cos, sin)
+    assert _maxrel(qe, g["rope_qe"]) < 1e-6 and _maxrel(ke, g["rope_ke"]) < 1e-6
+    x = torch.from_numpy(g["rms_x"]).requires_grad_(True)
+    y = O.swiglu_mlp(x, torch.from_numpy(g["mlp_wg"]), torch.from_numpy(g["mlp_wu"]), torch.from_numpy(g["mlp_wd"]))
+    y.backward(torch.from_numpy(g["rms_gy"]))
+    assert _maxrel(y.detach(), g["mlp_y"]) < 1e-5
+    assert _maxrel(x.grad, g["mlp_gx"]) < 1e-5
+
+
+def test_decoder_layer_with_padding(golden_dir):
+    g = _load(golden_dir, "per_op.npz")
+    P = {"L." + k[len("layer_w::"):]: torch.from_numpy(g[k]).requires_grad_(True) for k in g.files if k.startswith("layer_w::")}
+    x = torch.from_numpy(g["rms_x"]).requires_grad_(True)
+    lens = g["layer_lens"].tolist()
+    S, d = x.shape[1], x.shape[2]
+    cos, sin = O.rope_cos_sin(S, d // 2)
+    y = O.decoder_layer(x, P, "L.", 2, lens, cos, sin)
+    # rows beyond lens are don't-care in the reference too (they see a fully masked row)
+    y.backward(torch.from_numpy(g["layer_gy"]))
+    assert _maxrel(y.detach()[0], g["layer_y"][0]) < 1e-5
+    assert _maxrel(y.detach()[1, :lens[1]], g["layer_y"][1, :lens[1]]) < 1e-5
+    assert _maxrel(x.grad[0], g["layer_gx"][0]) < 1e-5
+    assert _maxrel(x.grad[1, :lens[1]], g["layer_gx"][1, :lens[1]]) < 1e-5
+    for k in g.files:
+        if k.startswith("layer_g::"):
+            assert _maxrel(P["L." + k[len("layer_g::"):]].grad, g[k]) < 1e-5, k
+
+
+def test_projector(golden_dir):
+    g = _load(golden_dir, "per_op.npz")
+    P = {"model.mm_projector." + k[len("proj_w::"):]: torch.from_numpy(g[k]).requires_grad_(True)
+         for k in g.files if k.startswith("proj_w::")}
+    x = torch.from_numpy(g["proj_x"]).requires_grad_(True)
+    y = O.mm_projector(P, x)
+    y.backward(torch.from_numpy(g["proj_gy"]))
+    assert _maxrel(y.detach(), g["proj_y"]) < 1e-5
+    assert _maxrel(x.grad, g["proj_gx"]) < 1e-5
+    for k in g.files:
+        if k.startswith("proj_g::"):
+            assert _maxrel(P["model.mm_projector." + k[len("proj_g::"):]].grad, g[k]) < 1e-5
+
+
+def test_host_functions(golden_dir):
+    h = json.load(open(os.path.join(golden_dir, "host_functions.json")))
+    pin = h["pinpoints"]
+    for size, want in h["select_best_resolution"]:
+        assert list(O.select_best_resolution(tuple(size), [tuple(p) for p in pin])) == want
+    for size, want in h["anyres_grid_shape"]:
+        assert list(O.get_anyres_image_grid_shape(tuple(size), pin, 336)) == want
+    for shp, osz, want_shape, want_sum in h["unpad_shape"]:
+        t = torch.arange(int(np.prod(shp)), dtype=torch.float32).view(*shp)
+        u = O.unpad_image(t, tuple(osz))
+        assert list(u.shape) == want_shape and float(u.sum()) == want_sum
+
+    class Ids:
+        def __init__(self, ids):
+            self.input_ids = ids
+
+    class Tok:
+        bos_token_id = 1
+
+        def __call__(self, s):
+            return Ids([1] + [ord(c) for c in s])
+
+    for prompt, want in h["tokenizer_image_token"]:
+        assert O.tokenizer_image_token(prompt, Tok()) == want
+
+
+def _run_e2e(golden_dir, name, with_newline=False):
+    g = _load(golden_dir, name + ".npz")
+    meta = json.load(open(os.path.join(golden_dir, name + "_gradnorms.json")))
+    geo = GEOMETRIES[meta["geometry"]]
+    P = O.make_params(geo, seed=0, with_newline=with_newline)
+    for k, v in P.items():
+        if "vision_tower" not in k:
+            v.requires_grad_(True)
+    nimg = len([k for k in g.files if k.startswith("image") and k[5:].isdigit()])
+    images = [torch.from_numpy(g[f"image{i}"]) for i in range(nimg)]
+    cfg = {"mm_patch_merge_type": meta["merge_type"]}
+    if meta["pinpoints"]:
+        cfg["image_grid_pinpoints"] = meta["pinpoints"]
+    loss, logits, aux = O.llava_forward(P, geo, torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"]),
+                                        torch.from_numpy(g["labels"]), images,
+                                        image_sizes=[tuple(s) for s in g["image_sizes"].tolist()], cfg=cfg)
+    loss.backward()
+    return g, meta, P, loss, logits, aux
+
+
+def _check_common(g, meta, P, loss, logits, aux):
+    assert np.array_equal(aux["labels"].numpy(), g["splice_labels"])
+    assert np.array_equal(aux["attention_mask"].numpy(), g["splice_attention_mask"])
+    assert bool(g["splice_position_ids_is_none"])
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+    m = g["splice_attention_mask"]
+    for k, want in meta["grad_norms"].items():
+        if want is None:
+            assert P[k].grad is None, k
+        else:
+            got = float(P[k].grad.norm())
+            assert abs(got - want) <= 2e-4 * max(want, 1e-3), (k, got, want)
+    return m
+
+
+def test_e2e_toy(golden_dir):
+    g, meta, P, loss, logits, aux = _run_e2e(golden_dir, "toy_e2e")
+    m = _check_common(g, meta, P, loss, logits, aux)
+    assert _maxrel(aux["image_features"].detach(), g["image_features"]) < 1e-5
+    assert _maxrel(aux["inputs_embeds"].detach(), g["inputs_embeds"]) < 1e-5
+    lg = logits.detach().numpy()
+    assert _maxrel(lg[m], g["logits"][m]) < 1e-4
+    for k in g.files:
+        if k.startswith("grad::"):
+            assert _maxrel(P[k[6:]].grad, g[k]) < 1e-4, k
+
+
+def test_e2e_toy_anyres(golden_dir):
+    g, meta, P, loss, logits, aux = _run_e2e(golden_dir, "toy_anyres_e2e", with_newline=True)
+    m = _check_common(g, meta, P, loss, logits, aux)
+    assert _maxrel(aux["inputs_embeds"].detach(), g["inputs_embeds"]) < 1e-5
+    assert _maxrel(logits.detach().numpy()[m], g["logits"][m]) < 1e-4
+
+
+@pytest.mark.slow
+def test_e2e_config1(golden_dir):
+    g, meta, P, loss, logits, aux = _run_e2e(golden_dir, "config1_e2e")
+    _check_common(g, meta, P, loss, logits, aux)
+    lg = logits.detach().numpy()
+    assert _maxrel(lg[:, ::7, ::997], g["logits_slice"]) < 1e-4
+    assert abs(np.abs(lg).max() - float(g["logits_absmax"].max())) < 1e-4
