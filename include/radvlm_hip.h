@@ -1,0 +1,134 @@
+/* radvlm_hip.h -- C ABI of libradvlm_hip.so: the MI355X (gfx950) kernels of the LLaVA training hot path.
+ *
+ * Drop-in boundary: the reference (rfahrn/RadVLM) has no C/FFI surface of its own -- its
+ * hot path bottoms out in torch/HF Python calls.  Each entry point below therefore names the reference call site
+ * (file:line under /root/reference/finetuning/llava, or HF: = transformers as pinned by the reference) whose
+ * arithmetic it replaces.  Conventions for every function:
+ *   - plain device pointers + sizes, no torch types; bf16 = raw uint16 storage; strides (ld*) in ELEMENTS;
+ *   - asynchronous on `stream` (a hipStream_t), no allocation, no host sync, no global state;
+ *   - `zeros16` is any 16-byte-aligned device buffer of >= 16 zero bytes (source for out-of-range tile chunks);
+ *   - returns 0 (RV_OK) or a negative error code (RV_ERR_*), which the Python binding raises as an exception.
+ */
+#ifndef RADVLM_HIP_H
+#define RADVLM_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RV_ACT_NONE 0
+#define RV_ACT_QUICK_GELU 1 /* x*sigmoid(1.702x): HF:activations.py QuickGELUActivation (CLIP MLP) */
+#define RV_ACT_GELU 2       /* erf GELU: torch.nn.GELU in multimodal_projector/builder.py:44 */
+
+/* Library version / build arch string ("gfx950"). */
+const char* rv_version(void);
+
+/* ---- GEMM -------------------------------------------------------------------------------------------------
+ * C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]) + residual[M,N]          (bf16 in, fp32 accumulate)
+ * = torch.nn.functional.linear at: modeling_llama.py:332-338,377 (q/k/v/o), :226 (gate/up/down), :1323 (lm_head);
+ *   HF:models/clip/modeling_clip.py:298-350 (CLIP q/k/v/out/fc1/fc2), :209 (patch conv as GEMM over im2col rows);
+ *   multimodal_projector/builder.py:41-48.  Backward (dgrad/wgrad) uses the same entry with transposed copies.
+ * K % 8 == 0, lda % 8 == 0, ldb % 8 == 0.  out_f32: C is fp32 (else bf16).  residual may alias C (accumulate).
+ */
+int rv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
+                    const void* residual, int64_t ldr, int M, int N, int K, int act, int out_f32, int res_f32,
+                    const void* zeros16, void* stream);
+
+/* Batched strided transpose of bf16 matrices: out[bz][c][r] = in[bz][r][c], r < R, c < C; columns r in [R, R_pad)
+ * of every output row are written as zero.  bz = b0 * nb1 + b1; offsets in elements.
+ * Used for: W^T copies (dgrad), X^T / dY^T (wgrad), and the [b,h,hd,S_pad] head-transposed attention operands. */
+int rv_transpose_bf16(const void* in, int64_t in_ld, int64_t in_bs0, int64_t in_bs1, void* out, int64_t out_ld,
+                      int64_t out_bs0, int64_t out_bs1, int R, int C, int R_pad, int nb0, int nb1, void* stream);
+
+/* ---- normalisation ------------------------------------------------------------------------------------------
+ * LlamaRMSNorm.forward (modeling_llama.py:82-87): y = w * bf16(x * rsqrt(mean(x^2) + eps)), fp32 internal.
+ * rstd (fp32 [rows], optional) is saved for backward. */
+int rv_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows, int d, float eps, void* stream);
+/* dx = rstd * (w*dy - xhat * mean(w*dy*xhat)); dw_partial[blk, d] (fp32, nblk rows) holds per-block sums of dy*xhat
+ * (finish with rv_colsum_f32).  If dx_add != 0, dx += (residual-stream gradient accumulation). */
+int rv_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, int dx_add,
+                   float* dw_partial, int nblk, int rows, int d, void* stream);
+/* torch.nn.LayerNorm forward as used by CLIP (HF:modeling_clip.py:362-384, pre_layrnorm :744). */
+int rv_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int rows, int d, float eps, void* stream);
+
+/* out[c] (+)= sum_r in[r, c]  (fp32 partial rows -> bf16 vector). */
+int rv_colsum_f32(const float* in, int rows, int cols, void* out_bf16, int accumulate, void* stream);
+/* partial[blk, c] = sum over the block's rows of x[r, c]  (bf16 [rows, cols] with stride ld -> fp32 [nblk, cols]);
+ * bias gradients of nn.Linear. */
+int rv_colsum_partial_bf16(const void* x, int64_t ld, int rows, int cols, float* partial, int nblk, void* stream);
+
+/* ---- rotary embedding ------------------------------------------------------------------------------------------
+ * apply_rotary_pos_emb (modeling_llama.py:167-198), half-split convention, in place on `nsec` consecutive
+ * [heads*hd] sections of each token row (q and k of a fused qkv row).  cos_sin: fp32 [S, hd/2, 2];
+ * position = row % S (position_ids = arange(S) for every sample, llava_arch.py:534-545).  dir = +1 fwd, -1 bwd. */
+int rv_rope_inplace(void* x, int64_t ld, const float* cos_sin, int rows, int S, int heads, int hd, int nsec, int dir,
+                    void* stream);
+
+/* ---- attention ----------------------------------------------------------------------------------------------------
+ * softmax_fp32(scale * Q K^T + causal + key-padding) V: modeling_llama.py:349-368 + :1191-1225,
+ * llama_flash_attn_monkey_patch.py:51-69; non-causal for HF:modeling_clip.py:259-277.
+ * q/k/out: token-major [(b*S+s)*ld + h*hd + e]; vT: [b,h,hd,S_pad] (zero padded); lse: fp32 [b,h,S_pad];
+ * lens (optional int32 [B]): valid keys per sample (right padding).  hd in {64,128}; S_pad % 64 == 0. */
+int rv_attn_fwd(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* vT, void* out, int64_t ld_o,
+                float* lse, const int32_t* lens, int B, int H, int S, int S_pad, int hd, int causal, float scale,
+                const void* zeros16, void* stream);
+/* Backward of the above: delta = rowsum(dO*O); dQ (query-block pass), dK/dV (key-block pass).
+ * qT/kT/doT are [b,h,hd,S_pad] transposed copies of q, k, dout (rv_transpose_bf16). */
+int rv_attn_bwd(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v, const void* o,
+                int64_t ld_o, const void* dout, int64_t ld_do, const void* qT, const void* kT, const void* doT,
+                const float* lse, float* delta, void* dq, int64_t ld_dq, void* dk, int64_t ld_dk, void* dv,
+                int64_t ld_dv, const int32_t* lens, int B, int H, int S, int S_pad, int hd, int causal, float scale,
+                const void* zeros16, void* stream);
+
+/* ---- MLP activations ------------------------------------------------------------------------------------------------
+ * LlamaMLP (modeling_llama.py:226): act[r, f] = silu(gu[r, f]) * gu[r, F + f]   (gu = fused gate|up output). */
+int rv_swiglu_fwd(const void* gu, int64_t ld_gu, void* act, int64_t ld_act, int rows, int F, void* stream);
+int rv_swiglu_bwd(const void* dact, int64_t ld_dact, const void* gu, int64_t ld_gu, void* dgu, int64_t ld_dgu, int rows,
+                  int F, void* stream);
+/* torch.nn.GELU (erf) of the mm_projector (multimodal_projector/builder.py:44) and its derivative. */
+int rv_gelu_fwd(const void* x, void* y, int64_t n, void* stream);
+int rv_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);
+
+/* ---- loss ----------------------------------------------------------------------------------------------------------
+ * LlamaForCausalLM loss (modeling_llama.py:1323-1337): logits.float(), CE with ignore_index -100.
+ * labels[r] is the ALREADY SHIFTED target of row r.  loss_rows[r] = -log softmax(logits[r])[label] (0 if ignored).
+ * If dlogits != NULL: dlogits[r] = (softmax - onehot) * inv_count (0 rows if ignored); may alias logits. */
+int rv_cross_entropy(const void* logits, int64_t ld, const int64_t* labels, float* loss_rows, void* dlogits,
+                     int64_t ld_d, int rows, int V, float inv_count, void* stream);
+/* out[0] = scale * sum(in[0..n))  (deterministic, single block). */
+int rv_sum_f32(const float* in, int64_t n, float scale, float* out, void* stream);
+
+/* ---- embedding splice ---------------------------------------------------------------------------------------------
+ * prepare_inputs_labels_for_multimodal steps (vi)-(viii), llava_arch.py:449-531, as one gather:
+ * dst[r] = idx[r] >= 0 ? table_a[idx[r]] : (idx[r] == -1 ? 0 : table_b[-idx[r] - 2]).  (exact-zero pad rows) */
+int rv_gather_rows(void* dst, int64_t ld_dst, const void* table_a, int64_t ld_a, const void* table_b, int64_t ld_b,
+                   const int32_t* idx, int rows, int d, void* stream);
+/* Embedding gradient without atomics: for segment s, out[out_row[s]] = sum_{j in [off[s], off[s+1])} src[pos[j]]. */
+int rv_segment_sum_rows(const void* src, int64_t ld_src, const int32_t* seg_off, const int32_t* pos,
+                        const int32_t* out_row, int nseg, void* out, int64_t ld_out, int d, void* stream);
+
+/* ---- CLIP embeddings -----------------------------------------------------------------------------------------------
+ * HF:modeling_clip.py:202-218: patches of pix [n,3,H,W] (bf16) -> rows [n*gh*gw, Kp], k = c*p*p + i*p + j (zero
+ * padded to Kp); then out[n, 0] = cls + pos[0], out[n, 1+i] = patch_out[n, i] + pos[1+i]. */
+int rv_im2col_patches(const void* pix, void* out, int n, int H, int W, int p, int Kp, void* stream);
+int rv_clip_embed(const void* patch_out, const void* cls, const void* pos, void* out, int n, int P, int d, void* stream);
+
+/* ---- optimizer / misc ----------------------------------------------------------------------------------------------
+ * torch.optim.AdamW step (optim="adamw_torch", train/train.py:140) on a flat slice: fp32 master/m/v, bf16 params and
+ * grads; grad is multiplied by *gscale (device scalar, e.g. the clip coefficient) if gscale != NULL. */
+int rv_adamw(void* p_bf16, float* master, const void* g_bf16, float* m, float* v, int64_t n, float lr, float b1,
+             float b2, float eps, float wd, float bc1, float bc2, const float* gscale, void* stream);
+/* partial[blk] = sum of squares of the block's slice (fp32); finish with rv_clip_coef. */
+int rv_sumsq_partial_bf16(const void* g, int64_t n, float* partial, int nblk, void* stream);
+/* norm = sqrt(sum partial); out[0] = norm, out[1] = min(1, max_norm / (norm + 1e-6))  (torch clip_grad_norm_). */
+int rv_clip_coef(const float* partial, int nblk, float max_norm, float* out2, void* stream);
+int rv_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream);
+int rv_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream);
+/* y[i] = a[i] + b[i] (bf16). */
+int rv_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

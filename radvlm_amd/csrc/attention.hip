@@ -1,0 +1,519 @@
+// Fused (flash-style) multi-head attention for gfx950, forward and backward, bf16 I/O, fp32 softmax.
+//
+// Replaces: LlamaAttention core  softmax_fp32(QK^T/sqrt(hd) + causal + key-padding) V
+//   (finetuning/llava/model/language_model/modeling_llama.py:349-368, mask :1191-1225; fused contract
+//    finetuning/llava/train/llama_flash_attn_monkey_patch.py:51-69: causal, key padding, dropout 0, scale 1/sqrt(hd))
+//   and CLIPAttention's non-causal MHSA (HF:models/clip/modeling_clip.py:259-277,298-335), plus their autograd backward.
+//
+// MFMA: v_mfma_f32_16x16x32_bf16 only. Every operand is read contraction-contiguous from an XOR-swizzled LDS
+// tile (ds_read_b128 / ds_read_b64); operands whose contraction index is the sequence axis come from
+// pre-transposed global copies [b,h,hd,S_pad] (rv_transpose_bf16), so no LDS transposes are needed.
+// The score tile produced by one MFMA chain is reused as the next chain's B operand straight from the
+// accumulator registers (contraction order kappa(g,j) = 16*(2p + (j>>2)) + 4g + (j&3), matched by the A-side reads).
+//
+// Layouts: q,k,v,o,dq,dk,dv,dO are token-major rows [(b*S+s)*ld + h*HD + e]; lse/delta are fp32 [b,h,S_pad].
+#include "common.h"
+#include "radvlm_hip.h"
+
+namespace {
+
+struct AttnParams {
+    const bf16 *q, *k, *v, *o, *dout;   // natural (token-major) operands
+    const bf16 *qT, *kT, *vT, *doT;     // transposed copies [b,h,HD,S_pad]
+    bf16 *out, *dq, *dk, *dv;
+    float *lse, *delta;
+    const int* lens;
+    const bf16* zeros;
+    long ld_q, ld_k, ld_v, ld_o, ld_do, ld_dq, ld_dk, ld_dv;
+    int B, H, S, S_pad;
+    float scale;
+};
+
+template <int ROW_BYTES> DEVINL int swz(int r) { return ROW_BYTES == 128 ? ((r >> 1) & 7) : (r & 15); }
+
+// Stage NROWS rows of ROW_BYTES each into an LDS tile; rows >= valid_rows come from the zero page.
+template <int ROW_BYTES, int NROWS>
+DEVINL void stage_rows(const bf16* src, long row_stride, int valid_rows, const bf16* zeros, char* lds, int wid, int lane) {
+    constexpr int CPR = ROW_BYTES / 16;
+    constexpr int NI = NROWS * CPR / 64;  // wave-instructions for the tile
+#pragma unroll
+    for (int i = 0; i < NI / 4; ++i) {
+        const int it = i * 4 + wid;
+        const int c = it * 64 + lane;
+        const int r = c / CPR, p = c % CPR;
+        const int lc = p ^ swz<ROW_BYTES>(r);
+        const bf16* g = (r < valid_rows) ? (src + (long)r * row_stride + lc * 8) : zeros;
+        glds16(g, lds + it * 1024);
+    }
+}
+
+template <int ROW_BYTES> DEVINL bf16x8 rd128(const char* tile, int row, int chunk) {
+    return *(const bf16x8*)(tile + row * ROW_BYTES + ((chunk ^ swz<ROW_BYTES>(row)) << 4));
+}
+// A-operand for a contraction over the tile's 64 columns in kappa order: pair p in {0,1}, lane group g.
+DEVINL bf16x8 rdT(const char* tile, int row, int p, int g) {
+    const int s = swz<128>(row);
+    const bf16x4 lo = *(const bf16x4*)(tile + row * 128 + (((4 * p + (g >> 1)) ^ s) << 4) + ((g & 1) << 3));
+    const bf16x4 hi = *(const bf16x4*)(tile + row * 128 + (((4 * p + 2 + (g >> 1)) ^ s) << 4) + ((g & 1) << 3));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+DEVINL bf16x8 pack8(f32x4 a, f32x4 b) {
+    return bf16x8{f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
+}
+DEVINL float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
+    constexpr int KS = HD / 32, DB = HD / 16, KROW = HD * 2;
+    constexpr int KT_BYTES = 64 * KROW, VT_BYTES = HD * 128, STAGE = KT_BYTES + VT_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wid = wave_id(), lane = lane_id(), g = lane >> 4, c = lane & 15;
+    const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int S = P.S, q0 = qblk * 128 + wid * 32;
+    const int len = P.lens ? P.lens[b] : S;
+    const float sl2 = P.scale * LOG2E;
+
+    bf16x8 qf[2][KS];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        const int row = min(q0 + qs * 16 + c, S - 1);
+        const bf16* p = P.q + (long)(b * S + row) * P.ld_q + h * HD + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[qs][ks] = *(const bf16x8*)(p + ks * 32);
+    }
+    const int kv_end = CAUSAL ? min(len, qblk * 128 + 128) : len;
+    const int ntiles = (kv_end + 63) >> 6;
+    const bf16* kbase = P.k + (long)b * S * P.ld_k + h * HD;
+    const bf16* vtbase = P.vT + (long)(b * P.H + h) * HD * P.S_pad;
+
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+    f32x4 o[2][DB];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) o[qs][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    stage_rows<KROW, 64>(kbase, P.ld_k, S, P.zeros, smem, wid, lane);
+    stage_rows<128, HD>(vtbase, P.S_pad, HD, P.zeros, smem + KT_BYTES, wid, lane);
+
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* Kt = smem + (t & 1) * STAGE;
+        const char* Vt = Kt + KT_BYTES;
+        if (t + 1 < ntiles) {
+            char* nx = smem + ((t + 1) & 1) * STAGE;
+            const int kv1 = (t + 1) * 64;
+            stage_rows<KROW, 64>(kbase + (long)kv1 * P.ld_k, P.ld_k, S - kv1, P.zeros, nx, wid, lane);
+            stage_rows<128, HD>(vtbase + kv1, P.S_pad, HD, P.zeros, nx + KT_BYTES, wid, lane);
+        }
+        const int kv0 = t * 64;
+        if (CAUSAL && kv0 > q0 + 31) continue;  // every key of this tile is in the future of this wave's rows
+
+        f32x4 s[2][4];
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) s[qs][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = rd128<KROW>(Kt, kb * 16 + c, ks * 4 + g);
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs) s[qs][kb] = mfma16(kf, qf[qs][ks], s[qs][kb]);
+            }
+        // lane holds S^T[key = kv0 + 16kb + 4g + r][q = q0 + 16qs + c]
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            const int qidx = q0 + qs * 16 + c;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kidx = kv0 + kb * 16 + 4 * g + r;
+                    const bool ok = (kidx < len) && (!CAUSAL || kidx <= qidx);
+                    const float tv = ok ? s[qs][kb][r] * sl2 : -INFINITY;
+                    s[qs][kb][r] = tv;
+                    mx = fmaxf(mx, tv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(m[qs], mx);
+            const float alpha = fexp2(m[qs] - mnew);
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = fexp2(s[qs][kb][r] - mnew);
+                    s[qs][kb][r] = p;
+                    rs += p;
+                }
+            l[qs] = l[qs] * alpha + rs;
+            m[qs] = mnew;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) o[qs][db] *= alpha;
+        }
+        // O^T[d][q] += V^T[d][key] P^T[key][q]
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) {
+            bf16x8 pf[2];
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) pf[qs] = pack8(s[qs][2 * kp], s[qs][2 * kp + 1]);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const bf16x8 vf = rdT(Vt, db * 16 + c, kp, g);
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs) o[qs][db] = mfma16(vf, pf[qs], o[qs][db]);
+            }
+        }
+    }
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        float lt = l[qs];
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        const int qidx = q0 + qs * 16 + c;
+        if (qidx >= S) continue;
+        const float inv = 1.f / lt;
+        bf16* op = P.out + (long)(b * S + qidx) * P.ld_o + h * HD + 4 * g;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            const f32x4 v = o[qs][db] * inv;
+            *(bf16x4*)(op + db * 16) = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        }
+        if (g == 0 && P.lse) P.lse[(long)(b * P.H + h) * P.S_pad + qidx] = (m[qs] + __builtin_amdgcn_logf(lt)) * LN2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
+__global__ void attn_delta_kernel(AttnParams P, int HD) {
+    // one wave per (token row, head)
+    const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = lane_id();
+    const int total = P.B * P.S * P.H;
+    if (wid >= total) return;
+    const int h = wid % P.H, row = wid / P.H;
+    const bf16* o = P.o + (long)row * P.ld_o + h * HD;
+    const bf16* d = P.dout + (long)row * P.ld_do + h * HD;
+    float acc = 0.f;
+    for (int e = lane * 2; e < HD; e += 128) {
+        const bf16x2 a = *(const bf16x2*)(o + e), bb = *(const bf16x2*)(d + e);
+        acc += bf2f(a[0]) * bf2f(bb[0]) + bf2f(a[1]) * bf2f(bb[1]);
+    }
+    acc = wave_sum(acc);
+    const int b = row / P.S, s = row % P.S;
+    if (lane == 0) P.delta[(long)(b * P.H + h) * P.S_pad + s] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P) {
+    constexpr int KS = HD / 32, DB = HD / 16, KROW = HD * 2;
+    constexpr int NAT_BYTES = 64 * KROW, T_BYTES = HD * 128, STAGE = 2 * NAT_BYTES + T_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wid = wave_id(), lane = lane_id(), g = lane >> 4, c = lane & 15;
+    const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int S = P.S, q0 = qblk * 128 + wid * 32;
+    const int len = P.lens ? P.lens[b] : S;
+    const float sl2 = P.scale * LOG2E;
+
+    bf16x8 qf[2][KS], dof[2][KS];
+    float lse2[2], dl[2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        const int row = min(q0 + qs * 16 + c, S - 1);
+        const bf16* p = P.q + (long)(b * S + row) * P.ld_q + h * HD + g * 8;
+        const bf16* d = P.dout + (long)(b * S + row) * P.ld_do + h * HD + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { qf[qs][ks] = *(const bf16x8*)(p + ks * 32); dof[qs][ks] = *(const bf16x8*)(d + ks * 32); }
+        lse2[qs] = P.lse[(long)(b * P.H + h) * P.S_pad + row] * LOG2E;
+        dl[qs] = P.delta[(long)(b * P.H + h) * P.S_pad + row];
+    }
+    const int kv_end = CAUSAL ? min(len, qblk * 128 + 128) : len;
+    const int ntiles = (kv_end + 63) >> 6;
+    const bf16* kbase = P.k + (long)b * S * P.ld_k + h * HD;
+    const bf16* vbase = P.v + (long)b * S * P.ld_v + h * HD;
+    const bf16* ktbase = P.kT + (long)(b * P.H + h) * HD * P.S_pad;
+
+    f32x4 dq[2][DB];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) dq[qs][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    stage_rows<KROW, 64>(kbase, P.ld_k, S, P.zeros, smem, wid, lane);
+    stage_rows<KROW, 64>(vbase, P.ld_v, S, P.zeros, smem + NAT_BYTES, wid, lane);
+    stage_rows<128, HD>(ktbase, P.S_pad, HD, P.zeros, smem + 2 * NAT_BYTES, wid, lane);
+
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* Kt = smem + (t & 1) * STAGE;
+        const char* Vt = Kt + NAT_BYTES;
+        const char* KTt = Kt + 2 * NAT_BYTES;
+        if (t + 1 < ntiles) {
+            char* nx = smem + ((t + 1) & 1) * STAGE;
+            const int kv1 = (t + 1) * 64;
+            stage_rows<KROW, 64>(kbase + (long)kv1 * P.ld_k, P.ld_k, S - kv1, P.zeros, nx, wid, lane);
+            stage_rows<KROW, 64>(vbase + (long)kv1 * P.ld_v, P.ld_v, S - kv1, P.zeros, nx + NAT_BYTES, wid, lane);
+            stage_rows<128, HD>(ktbase + kv1, P.S_pad, HD, P.zeros, nx + 2 * NAT_BYTES, wid, lane);
+        }
+        const int kv0 = t * 64;
+        if (CAUSAL && kv0 > q0 + 31) continue;
+
+        f32x4 s[2][4], dp[2][4];
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) { s[qs][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qs][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 kf = rd128<KROW>(Kt, kb * 16 + c, ks * 4 + g);
+                const bf16x8 vf = rd128<KROW>(Vt, kb * 16 + c, ks * 4 + g);
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs) {
+                    s[qs][kb] = mfma16(kf, qf[qs][ks], s[qs][kb]);
+                    dp[qs][kb] = mfma16(vf, dof[qs][ks], dp[qs][kb]);
+                }
+            }
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            const int qidx = q0 + qs * 16 + c;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kidx = kv0 + kb * 16 + 4 * g + r;
+                    const bool ok = (kidx < len) && (!CAUSAL || kidx <= qidx);
+                    const float p = fexp2(s[qs][kb][r] * sl2 - lse2[qs]);
+                    s[qs][kb][r] = ok ? p * (dp[qs][kb][r] - dl[qs]) : 0.f;
+                }
+        }
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp) {
+            bf16x8 dsf[2];
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) dsf[qs] = pack8(s[qs][2 * kp], s[qs][2 * kp + 1]);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const bf16x8 ktf = rdT(KTt, db * 16 + c, kp, g);
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs) dq[qs][db] = mfma16(ktf, dsf[qs], dq[qs][db]);
+            }
+        }
+    }
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        const int qidx = q0 + qs * 16 + c;
+        if (qidx >= S) continue;
+        bf16* op = P.dq + (long)(b * S + qidx) * P.ld_dq + h * HD + 4 * g;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            const f32x4 v = dq[qs][db] * P.scale;
+            *(bf16x4*)(op + db * 16) = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P) {
+    constexpr int KS = HD / 32, DB = HD / 16, KROW = HD * 2;
+    constexpr int NAT_BYTES = 64 * KROW, T_BYTES = HD * 128, STAGE = 2 * NAT_BYTES + 2 * T_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wid = wave_id(), lane = lane_id(), g = lane >> 4, c = lane & 15;
+    const int kblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int S = P.S, k0 = kblk * 128 + wid * 32;
+    const int len = P.lens ? P.lens[b] : S;
+    const float sl2 = P.scale * LOG2E;
+
+    bf16x8 kf[2][KS], vf[2][KS];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int row = min(k0 + kb * 16 + c, S - 1);
+        const bf16* kp = P.k + (long)(b * S + row) * P.ld_k + h * HD + g * 8;
+        const bf16* vp = P.v + (long)(b * S + row) * P.ld_v + h * HD + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { kf[kb][ks] = *(const bf16x8*)(kp + ks * 32); vf[kb][ks] = *(const bf16x8*)(vp + ks * 32); }
+    }
+    const int q_end = len;  // query rows >= len carry zero dO
+    const int t0 = CAUSAL ? (kblk * 128) >> 6 : 0;
+    const int t1 = (q_end + 63) >> 6;
+    const bf16* qbase = P.q + (long)b * S * P.ld_q + h * HD;
+    const bf16* dobase = P.dout + (long)b * S * P.ld_do + h * HD;
+    const bf16* qtbase = P.qT + (long)(b * P.H + h) * HD * P.S_pad;
+    const bf16* dotbase = P.doT + (long)(b * P.H + h) * HD * P.S_pad;
+    const float* lsebase = P.lse + (long)(b * P.H + h) * P.S_pad;
+    const float* dlbase = P.delta + (long)(b * P.H + h) * P.S_pad;
+
+    f32x4 dv[DB][2], dk[DB][2];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) { dv[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    auto stage = [&](int t, char* dst) {
+        const int qt0 = t * 64;
+        stage_rows<KROW, 64>(qbase + (long)qt0 * P.ld_q, P.ld_q, S - qt0, P.zeros, dst, wid, lane);
+        stage_rows<KROW, 64>(dobase + (long)qt0 * P.ld_do, P.ld_do, S - qt0, P.zeros, dst + NAT_BYTES, wid, lane);
+        stage_rows<128, HD>(qtbase + qt0, P.S_pad, HD, P.zeros, dst + 2 * NAT_BYTES, wid, lane);
+        stage_rows<128, HD>(dotbase + qt0, P.S_pad, HD, P.zeros, dst + 2 * NAT_BYTES + T_BYTES, wid, lane);
+    };
+    if (t0 < t1) stage(t0, smem);
+
+    for (int t = t0; t < t1; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* Qt = smem + ((t - t0) & 1) * STAGE;
+        const char* dOt = Qt + NAT_BYTES;
+        const char* QTt = Qt + 2 * NAT_BYTES;
+        const char* dOTt = QTt + T_BYTES;
+        if (t + 1 < t1) stage(t + 1, smem + ((t + 1 - t0) & 1) * STAGE);
+        const int qt0 = t * 64;
+        if (CAUSAL && qt0 + 63 < k0) continue;  // every query of this tile precedes this wave's keys
+
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+            f32x4 s[2][2], dp[2][2];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) { s[qq][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qq][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int qb = 2 * qp + qq;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 qa = rd128<KROW>(Qt, qb * 16 + c, ks * 4 + g);
+                    const bf16x8 da = rd128<KROW>(dOt, qb * 16 + c, ks * 4 + g);
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb) {
+                        s[qq][kb] = mfma16(qa, kf[kb][ks], s[qq][kb]);
+                        dp[qq][kb] = mfma16(da, vf[kb][ks], dp[qq][kb]);
+                    }
+                }
+            }
+            // lane holds S[q = qt0 + 16qb + 4g + r][key = k0 + 16kb + c]
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int qrow = qt0 + (2 * qp + qq) * 16 + 4 * g;
+                const f32x4 ls = *(const f32x4*)(lsebase + qrow);
+                const f32x4 dl = *(const f32x4*)(dlbase + qrow);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const int kidx = k0 + kb * 16 + c;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qidx = qrow + r;
+                        const bool ok = (kidx < len) && (qidx < q_end) && (!CAUSAL || kidx <= qidx);
+                        const float p = fexp2(s[qq][kb][r] * sl2 - ls[r] * LOG2E);
+                        s[qq][kb][r] = ok ? p : 0.f;
+                        dp[qq][kb][r] = ok ? p * (dp[qq][kb][r] - dl[r]) : 0.f;
+                    }
+                }
+            }
+            bf16x8 pf[2], dsf[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) { pf[kb] = pack8(s[0][kb], s[1][kb]); dsf[kb] = pack8(dp[0][kb], dp[1][kb]); }
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const bf16x8 dota = rdT(dOTt, db * 16 + c, qp, g);
+                const bf16x8 qta = rdT(QTt, db * 16 + c, qp, g);
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    dv[db][kb] = mfma16(dota, pf[kb], dv[db][kb]);
+                    dk[db][kb] = mfma16(qta, dsf[kb], dk[db][kb]);
+                }
+            }
+        }
+    }
+    // lane holds dV^T[d = 16db + 4g + r][key = k0 + 16kb + c]
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int kidx = k0 + kb * 16 + c;
+        if (kidx >= S) continue;
+        bf16* vp = P.dv + (long)(b * S + kidx) * P.ld_dv + h * HD + 4 * g;
+        bf16* kp = P.dk + (long)(b * S + kidx) * P.ld_dk + h * HD + 4 * g;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            const f32x4 a = dv[db][kb], bb = dk[db][kb] * P.scale;
+            *(bf16x4*)(vp + db * 16) = bf16x4{f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3])};
+            *(bf16x4*)(kp + db * 16) = bf16x4{f2bf(bb[0]), f2bf(bb[1]), f2bf(bb[2]), f2bf(bb[3])};
+        }
+    }
+}
+
+template <typename K>
+int set_smem(K kern, int bytes) {
+    return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : -1;
+}
+
+bool aligned_ok(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int rv_attn_fwd(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* vT, void* out,
+                           int64_t ld_o, float* lse, const int32_t* lens, int B, int H, int S, int S_pad, int HD,
+                           int causal, float scale, const void* zeros16, void* stream) {
+    if (!q || !k || !vT || !out || !zeros16 || B <= 0 || H <= 0 || S <= 0) return RV_ERR_ARG;
+    if ((HD != 64 && HD != 128) || (S_pad & 63) || S_pad < S) return RV_ERR_ARG;
+    if ((ld_q & 7) || (ld_k & 7) || (ld_o & 3) || !aligned_ok(q) || !aligned_ok(k) || !aligned_ok(vT)) return RV_ERR_ARG;
+    AttnParams P = {};
+    P.q = (const bf16*)q; P.k = (const bf16*)k; P.vT = (const bf16*)vT; P.out = (bf16*)out; P.lse = lse; P.lens = lens;
+    P.zeros = (const bf16*)zeros16; P.ld_q = ld_q; P.ld_k = ld_k; P.ld_o = ld_o;
+    P.B = B; P.H = H; P.S = S; P.S_pad = S_pad; P.scale = scale;
+    dim3 grid((S + 127) / 128, H, B);
+    const int smem = 2 * (64 * HD * 2 + HD * 128);
+#define LAUNCH_FWD(HD_, C_)                                                                             \
+    do {                                                                                                \
+        set_smem(attn_fwd_kernel<HD_, C_>, smem);                                                       \
+        hipLaunchKernelGGL((attn_fwd_kernel<HD_, C_>), grid, dim3(256), smem, (hipStream_t)stream, P); \
+    } while (0)
+    if (HD == 128) { if (causal) LAUNCH_FWD(128, true); else LAUNCH_FWD(128, false); }
+    else { if (causal) LAUNCH_FWD(64, true); else LAUNCH_FWD(64, false); }
+#undef LAUNCH_FWD
+    return rv_check_launch();
+}
+
+extern "C" int rv_attn_bwd(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v,
+                           const void* o, int64_t ld_o, const void* dout, int64_t ld_do, const void* qT, const void* kT,
+                           const void* doT, const float* lse, float* delta, void* dq, int64_t ld_dq, void* dk,
+                           int64_t ld_dk, void* dv, int64_t ld_dv, const int32_t* lens, int B, int H, int S, int S_pad,
+                           int HD, int causal, float scale, const void* zeros16, void* stream) {
+    if (!q || !k || !v || !o || !dout || !qT || !kT || !doT || !lse || !delta || !dq || !dk || !dv || !zeros16) return RV_ERR_ARG;
+    if ((HD != 64 && HD != 128) || (S_pad & 63) || S_pad < S || B <= 0 || H <= 0 || S <= 0) return RV_ERR_ARG;
+    if ((ld_q & 7) || (ld_k & 7) || (ld_v & 7) || (ld_do & 7) || (ld_o & 1) || (ld_dq & 3) || (ld_dk & 3) || (ld_dv & 3)) return RV_ERR_ARG;
+    if (!aligned_ok(q) || !aligned_ok(k) || !aligned_ok(v) || !aligned_ok(dout) || !aligned_ok(qT) || !aligned_ok(kT) || !aligned_ok(doT)) return RV_ERR_ARG;
+    AttnParams P = {};
+    P.q = (const bf16*)q; P.k = (const bf16*)k; P.v = (const bf16*)v; P.o = (const bf16*)o; P.dout = (const bf16*)dout;
+    P.qT = (const bf16*)qT; P.kT = (const bf16*)kT; P.doT = (const bf16*)doT;
+    P.dq = (bf16*)dq; P.dk = (bf16*)dk; P.dv = (bf16*)dv; P.lse = (float*)lse; P.delta = delta; P.lens = lens;
+    P.zeros = (const bf16*)zeros16;
+    P.ld_q = ld_q; P.ld_k = ld_k; P.ld_v = ld_v; P.ld_o = ld_o; P.ld_do = ld_do; P.ld_dq = ld_dq; P.ld_dk = ld_dk; P.ld_dv = ld_dv;
+    P.B = B; P.H = H; P.S = S; P.S_pad = S_pad; P.scale = scale;
+    hipStream_t st = (hipStream_t)stream;
+    const int nw = B * S * H;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((nw * 64 + 255) / 256), dim3(256), 0, st, P, HD);
+    dim3 grid((S + 127) / 128, H, B);
+    const int smem_dq = 2 * (2 * 64 * HD * 2 + HD * 128);
+    const int smem_dkv = 2 * (2 * 64 * HD * 2 + 2 * HD * 128);
+#define LAUNCH_BWD(HD_, C_)                                                                                    \
+    do {                                                                                                       \
+        set_smem(attn_bwd_dq_kernel<HD_, C_>, smem_dq);                                                        \
+        set_smem(attn_bwd_dkv_kernel<HD_, C_>, smem_dkv);                                                      \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_, C_>), grid, dim3(256), smem_dq, st, P);                    \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD_, C_>), grid, dim3(256), smem_dkv, st, P);                  \
+    } while (0)
+    if (HD == 128) { if (causal) LAUNCH_BWD(128, true); else LAUNCH_BWD(128, false); }
+    else { if (causal) LAUNCH_BWD(64, true); else LAUNCH_BWD(64, false); }
+#undef LAUNCH_BWD
+    return rv_check_launch();
+}

@@ -1,0 +1,260 @@
+"""Thin typed wrappers over the C ABI (radvlm_amd.lib): shape checks on the host, then one kernel launch.
+
+Names follow the reference's operators.  No op here has a torch fallback.
+"""
+import math
+
+import torch
+
+from . import lib
+from .lib import ACT_GELU, ACT_NONE, ACT_QUICK_GELU  # noqa: F401
+
+BF16 = torch.bfloat16
+
+
+def _chk(t, dtype=BF16):
+    assert t.is_cuda and t.dtype == dtype, (t.device, t.dtype)
+    return t
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def gemm_nt(a, b, out=None, bias=None, residual=None, act=ACT_NONE, out_dtype=BF16):
+    """out[M,N] = act(a[M,K] @ b[N,K]^T + bias) + residual.  a, b: 2-D bf16 views with unit inner stride."""
+    _chk(a), _chk(b)
+    M, K = a.shape
+    N, K2 = b.shape
+    assert K == K2 and a.stride(1) == 1 and b.stride(1) == 1
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype in (BF16, torch.float32)
+    if bias is not None:
+        _chk(bias)
+        assert bias.numel() == N and bias.is_contiguous()
+    res_f32 = 0
+    ldr = 0
+    if residual is not None:
+        assert residual.shape == (M, N) and residual.stride(1) == 1
+        res_f32 = int(residual.dtype == torch.float32)
+        ldr = residual.stride(0)
+    lib.call("rv_gemm_nt_bf16", a, a.stride(0), b, b.stride(0), out, out.stride(0), bias, residual, ldr, M, N, K, act,
+             int(out.dtype == torch.float32), res_f32, lib.zeros16(a.device))
+    return out
+
+
+def transpose(x, r_pad=None, out=None):
+    """x [R,C] (unit inner stride) -> [C, r_pad] with zero padding."""
+    _chk(x)
+    R, C = x.shape
+    r_pad = r_pad or round_up(R, 8)
+    if out is None:
+        out = torch.empty(C, r_pad, dtype=BF16, device=x.device)
+    assert out.shape == (C, r_pad) and out.stride(1) == 1 and x.stride(1) == 1
+    lib.call("rv_transpose_bf16", x, x.stride(0), 0, 0, out, out.stride(0), 0, 0, R, C, r_pad, 1, 1)
+    return out
+
+
+def transpose_heads(x, B, S, H, hd, s_pad, out=None):
+    """x: token-major view [(b*S+s), H*hd] (row stride ld) -> [B,H,hd,s_pad] (zero padded along s)."""
+    _chk(x)
+    assert x.shape == (B * S, H * hd) and x.stride(1) == 1
+    if out is None:
+        out = torch.empty(B, H, hd, s_pad, dtype=BF16, device=x.device)
+    ld = x.stride(0)
+    lib.call("rv_transpose_bf16", x, ld, S * ld, hd, out, s_pad, H * hd * s_pad, hd * s_pad, S, hd, s_pad, B, H)
+    return out
+
+
+def rmsnorm_fwd(x, w, eps=1e-5, y=None, rstd=None):
+    _chk(x), _chk(w)
+    rows, d = x.shape
+    assert x.is_contiguous()
+    y = torch.empty_like(x) if y is None else y
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device) if rstd is None else rstd
+    lib.call("rv_rmsnorm_fwd", x, w, y, rstd, rows, d, eps)
+    return y, rstd
+
+
+def rmsnorm_bwd(dy, x, w, rstd, dx=None, dx_add=False, dw=None, dw_accumulate=False):
+    rows, d = x.shape
+    assert dy.is_contiguous() and x.is_contiguous()
+    nblk = min(rows, 512)
+    part = torch.empty(nblk, d, dtype=torch.float32, device=x.device)
+    if dx is None:
+        dx = torch.empty_like(x)
+        dx_add = False
+    lib.call("rv_rmsnorm_bwd", dy, x, w, rstd, dx, int(dx_add), part, nblk, rows, d)
+    if dw is None:
+        dw = torch.empty(d, dtype=BF16, device=x.device)
+        dw_accumulate = False
+    lib.call("rv_colsum_f32", part, nblk, d, dw, int(dw_accumulate))
+    return dx, dw
+
+
+def layernorm_fwd(x, w, b, eps=1e-5, y=None):
+    rows, d = x.shape
+    assert x.is_contiguous()
+    y = torch.empty_like(x) if y is None else y
+    lib.call("rv_layernorm_fwd", x, w, b, y, rows, d, eps)
+    return y
+
+
+def bias_grad(dy, out=None, accumulate=False):
+    """db[c] = sum_r dy[r, c]."""
+    rows, cols = dy.shape
+    nblk = min(rows, 256)
+    part = torch.empty(nblk, cols, dtype=torch.float32, device=dy.device)
+    lib.call("rv_colsum_partial_bf16", dy, dy.stride(0), rows, cols, part, nblk)
+    if out is None:
+        out = torch.empty(cols, dtype=BF16, device=dy.device)
+        accumulate = False
+    lib.call("rv_colsum_f32", part, nblk, cols, out, int(accumulate))
+    return out
+
+
+def rope_table(S, hd, theta=10000.0, device="cuda", round_bf16=True):
+    """fp32 [S, hd/2, 2] (cos, sin); computed like LlamaRotaryEmbedding.forward (modeling_llama.py:123-139):
+    fp32 trig, then rounded through bf16 like the reference's ``.to(dtype=x.dtype)``."""
+    inv = 1.0 / (theta ** (torch.arange(0, hd, 2, dtype=torch.int64).float() / hd))
+    fr = torch.outer(torch.arange(S, dtype=torch.float32), inv)
+    cs = torch.stack((fr.cos(), fr.sin()), dim=-1)
+    if round_bf16:
+        cs = cs.to(BF16).float()
+    return cs.contiguous().to(device)
+
+
+def rope_inplace(x, cos_sin, S, heads, hd, nsec, direction=1):
+    rows = x.shape[0]
+    lib.call("rv_rope_inplace", x, x.stride(0), cos_sin, rows, S, heads, hd, nsec, direction)
+    return x
+
+
+def attn_fwd(q, k, vT, B, S, H, hd, s_pad, causal, lens=None, scale=None, out=None, lse=None):
+    """q, k: token-major [(B*S), H*hd] views; vT [B,H,hd,s_pad]. Returns (out [(B*S), H*hd], lse fp32 [B,H,s_pad])."""
+    scale = scale if scale is not None else 1.0 / math.sqrt(hd)
+    if out is None:
+        out = torch.empty(B * S, H * hd, dtype=BF16, device=q.device)
+    if lse is None:
+        lse = torch.zeros(B, H, s_pad, dtype=torch.float32, device=q.device)
+    lib.call("rv_attn_fwd", q, q.stride(0), k, k.stride(0), vT, out, out.stride(0), lse, lens, B, H, S, s_pad, hd,
+             int(causal), scale, lib.zeros16(q.device))
+    return out, lse
+
+
+def attn_bwd(q, k, v, o, dout, lse, B, S, H, hd, s_pad, causal, lens=None, scale=None, dq=None, dk=None, dv=None):
+    scale = scale if scale is not None else 1.0 / math.sqrt(hd)
+    dev = q.device
+    qT = transpose_heads(q, B, S, H, hd, s_pad)
+    kT = transpose_heads(k, B, S, H, hd, s_pad)
+    doT = transpose_heads(dout, B, S, H, hd, s_pad)
+    delta = torch.zeros(B, H, s_pad, dtype=torch.float32, device=dev)
+    dq = torch.empty(B * S, H * hd, dtype=BF16, device=dev) if dq is None else dq
+    dk = torch.empty(B * S, H * hd, dtype=BF16, device=dev) if dk is None else dk
+    dv = torch.empty(B * S, H * hd, dtype=BF16, device=dev) if dv is None else dv
+    lib.call("rv_attn_bwd", q, q.stride(0), k, k.stride(0), v, v.stride(0), o, o.stride(0), dout, dout.stride(0), qT, kT, doT,
+             lse, delta, dq, dq.stride(0), dk, dk.stride(0), dv, dv.stride(0), lens, B, H, S, s_pad, hd, int(causal), scale,
+             lib.zeros16(dev))
+    return dq, dk, dv
+
+
+def swiglu_fwd(gu, F, act=None):
+    rows = gu.shape[0]
+    if act is None:
+        act = torch.empty(rows, F, dtype=BF16, device=gu.device)
+    lib.call("rv_swiglu_fwd", gu, gu.stride(0), act, act.stride(0), rows, F)
+    return act
+
+
+def swiglu_bwd(dact, gu, F, dgu=None):
+    rows = gu.shape[0]
+    dgu = torch.empty_like(gu) if dgu is None else dgu
+    lib.call("rv_swiglu_bwd", dact, dact.stride(0), gu, gu.stride(0), dgu, dgu.stride(0), rows, F)
+    return dgu
+
+
+def gelu_fwd(x, y=None):
+    assert x.is_contiguous()
+    y = torch.empty_like(x) if y is None else y
+    lib.call("rv_gelu_fwd", x, y, x.numel())
+    return y
+
+
+def gelu_bwd(dy, x, dx=None):
+    assert x.is_contiguous() and dy.is_contiguous()
+    dx = torch.empty_like(x) if dx is None else dx
+    lib.call("rv_gelu_bwd", dy, x, dx, x.numel())
+    return dx
+
+
+def cross_entropy(logits, labels_shifted, V, inv_count, grad_inplace=True):
+    """Returns (loss scalar fp32 tensor [1], loss_rows). If grad_inplace, logits are overwritten by dlogits."""
+    rows = logits.shape[0]
+    loss_rows = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    dl = logits if grad_inplace else None
+    lib.call("rv_cross_entropy", logits, logits.stride(0), labels_shifted, loss_rows, dl, logits.stride(0) if grad_inplace else 0,
+             rows, V, inv_count)
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    lib.call("rv_sum_f32", loss_rows, rows, inv_count, loss)
+    return loss, loss_rows
+
+
+def gather_rows(idx, d, table_a, table_b=None, out=None):
+    rows = idx.numel()
+    assert idx.dtype == torch.int32
+    if out is None:
+        out = torch.empty(rows, d, dtype=BF16, device=idx.device)
+    lib.call("rv_gather_rows", out, out.stride(0), table_a, table_a.stride(0) if table_a is not None else 0, table_b,
+             table_b.stride(0) if table_b is not None else 0, idx, rows, d)
+    return out
+
+
+def segment_sum_rows(src, seg_off, pos, out_row, out):
+    nseg = out_row.numel()
+    if nseg == 0:
+        return out
+    lib.call("rv_segment_sum_rows", src, src.stride(0), seg_off, pos, out_row, nseg, out, out.stride(0), src.shape[1])
+    return out
+
+
+def im2col_patches(pix, p, kp):
+    n, c, H, W = pix.shape
+    assert c == 3 and pix.is_contiguous()
+    _chk(pix)
+    out = torch.empty(n * (H // p) * (W // p), kp, dtype=BF16, device=pix.device)
+    lib.call("rv_im2col_patches", pix, out, n, H, W, p, kp)
+    return out
+
+
+def clip_embed(patch_out, cls, pos, n, P, d):
+    out = torch.empty(n * (P + 1), d, dtype=BF16, device=patch_out.device)
+    lib.call("rv_clip_embed", patch_out, cls, pos, out, n, P, d)
+    return out
+
+
+def adamw(p, master, g, m, v, lr, b1, b2, eps, wd, step, gscale=None):
+    n = p.numel()
+    lib.call("rv_adamw", p, master, g, m, v, n, lr, b1, b2, eps, wd, 1.0 - b1 ** step, 1.0 - b2 ** step, gscale)
+
+
+def grad_norm_clip_coef(g, max_norm):
+    """Returns fp32[2] device tensor: (global grad norm, clip coefficient) with no host sync."""
+    nblk = 1024
+    part = torch.empty(nblk, dtype=torch.float32, device=g.device)
+    lib.call("rv_sumsq_partial_bf16", g, g.numel(), part, nblk)
+    out = torch.empty(2, dtype=torch.float32, device=g.device)
+    lib.call("rv_clip_coef", part, nblk, max_norm, out)
+    return out
+
+
+def to_bf16(x):
+    out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    lib.call("rv_cast_f32_to_bf16", x.contiguous(), out, x.numel())
+    return out
+
+
+def to_f32(x):
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    lib.call("rv_cast_bf16_to_f32", x.contiguous(), out, x.numel())
+    return out

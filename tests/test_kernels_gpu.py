@@ -1,0 +1,277 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): every HIP kernel, called through the C ABI
+(radvlm_amd.lib -> libradvlm_hip.so), against the CPU oracle (oracle/llava_oracle.py, torch fp32) on the same
+bf16-rounded inputs.  Tolerance: outputs are bf16 (8 significant bits), so the gate is
+max|d| / max|ref| <= 2^-7 (7.8e-3) unless stated; fp32 outputs (lse, loss, rstd) are held to 1e-4 or tighter.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from radvlm_amd import portable_rng as prng
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2.0 ** -7
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from radvlm_amd import lib, ops as _ops
+    lib.load()
+    return _ops
+
+
+def rnd(tag, shape, std=1.0):
+    return torch.from_numpy(prng.normal(11, tag, shape, std)).to(torch.bfloat16)
+
+
+def relerr(got, ref):
+    got = got.detach().float().cpu().double()
+    ref = ref.detach().float().cpu().double()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (16, 16, 32), (100, 200, 72), (256, 448, 256), (577, 1000, 128),
+                                   (300, 130, 1000), (1024, 512, 4096)])
+def test_gemm_plain(ops, M, N, K):
+    a, b = rnd(1, (M, K)), rnd(2, (N, K))
+    ref = a.float() @ b.float().t()
+    out = ops.gemm_nt(a.cuda(), b.cuda())
+    assert relerr(out, ref) < TOL
+    out32 = ops.gemm_nt(a.cuda(), b.cuda(), out_dtype=torch.float32)
+    assert relerr(out32, ref) < 1e-5
+
+
+def test_gemm_identity_asymmetric(ops):
+    # A = I with an asymmetric B catches a transposed C write (guide section 3)
+    K = 128
+    a = torch.eye(K, dtype=torch.bfloat16)
+    b = (torch.arange(96)[:, None] * 3 + torch.arange(K)[None, :] % 7).to(torch.bfloat16)
+    out = ops.gemm_nt(a.cuda(), b.cuda(), out_dtype=torch.float32)
+    assert torch.equal(out.cpu(), b.float().t().contiguous())
+
+
+def test_gemm_epilogues_and_strides(ops):
+    from oracle import llava_oracle as O
+    M, N, K = 200, 192, 128
+    big = rnd(3, (M, 3 * K)).cuda()
+    a = big[:, K:2 * K]                       # strided A view (fused-qkv style)
+    b = rnd(4, (N, K)).cuda()
+    bias = rnd(5, (N,), 0.5).cuda()
+    res = rnd(6, (M, N)).cuda()
+    base = a.float().cpu() @ b.float().cpu().t() + bias.float().cpu()
+    for act, fn in ((ops.ACT_NONE, lambda x: x), (ops.ACT_QUICK_GELU, O.quick_gelu), (ops.ACT_GELU, torch.nn.functional.gelu)):
+        out = ops.gemm_nt(a, b, bias=bias, residual=res, act=act)
+        assert relerr(out, fn(base) + res.float().cpu()) < TOL
+    # accumulate into an fp32 C (residual aliases C), written into a column slice of a wider buffer
+    wide = torch.zeros(M, 2 * N, dtype=torch.float32, device="cuda")
+    c = wide[:, N:]
+    c.copy_(res.float())
+    ops.gemm_nt(a, b, out=c, residual=c)
+    assert relerr(c, a.float().cpu() @ b.float().cpu().t() + res.float().cpu()) < 1e-5
+    assert float(wide[:, :N].abs().max()) == 0.0
+
+
+def test_transpose(ops):
+    x = rnd(7, (70, 104)).cuda()
+    t = ops.transpose(x, r_pad=128)
+    assert torch.equal(t[:, :70].cpu(), x.cpu().t())
+    assert float(t[:, 70:].float().abs().max()) == 0.0
+    B, S, H, hd = 2, 50, 3, 64
+    qkv = rnd(8, (B * S, 3 * H * hd)).cuda()
+    k = qkv[:, H * hd:2 * H * hd]
+    kt = ops.transpose_heads(k, B, S, H, hd, 64)
+    ref = k.cpu().view(B, S, H, hd).permute(0, 2, 3, 1)
+    assert torch.equal(kt[..., :S].cpu(), ref)
+    assert float(kt[..., S:].float().abs().max()) == 0.0
+
+
+def test_rmsnorm(ops):
+    from oracle import llava_oracle as O
+    rows, d = 77, 4096
+    x, w, dy = rnd(9, (rows, d)), (1 + rnd(10, (d,), 0.1).float()).to(torch.bfloat16), rnd(12, (rows, d))
+    xr, wr = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    y = O.rmsnorm(xr, wr)
+    y.backward(dy.float())
+    yg, rstd = ops.rmsnorm_fwd(x.cuda(), w.cuda())
+    assert relerr(yg, y) < TOL
+    assert relerr(rstd, torch.rsqrt(x.float().pow(2).mean(-1) + 1e-5)) < 1e-5
+    dx, dw = ops.rmsnorm_bwd(dy.cuda(), x.cuda(), w.cuda(), rstd)
+    assert relerr(dx, xr.grad) < TOL
+    assert relerr(dw, wr.grad) < TOL
+    # accumulate form
+    dx2 = dx.clone()
+    ops.rmsnorm_bwd(dy.cuda(), x.cuda(), w.cuda(), rstd, dx=dx2, dx_add=True, dw=dw.clone(), dw_accumulate=True)
+    assert relerr(dx2, 2 * xr.grad) < 2 * TOL
+
+
+def test_layernorm(ops):
+    rows, d = 61, 1024
+    x, w, b = rnd(13, (rows, d)), (1 + rnd(14, (d,), 0.1).float()).to(torch.bfloat16), rnd(15, (d,), 0.1)
+    ref = torch.nn.functional.layer_norm(x.float(), (d,), w.float(), b.float(), 1e-5)
+    assert relerr(ops.layernorm_fwd(x.cuda(), w.cuda(), b.cuda()), ref) < TOL
+
+
+def test_rope(ops):
+    from oracle import llava_oracle as O
+    B, S, H, hd = 2, 40, 2, 128
+    qkv = rnd(16, (B * S, 3 * H * hd))
+    cs = ops.rope_table(S, hd)
+    cos, sin = O.rope_cos_sin(S, hd)
+    cos, sin = cos.to(torch.bfloat16).float(), sin.to(torch.bfloat16).float()
+    q = qkv[:, :H * hd].float().view(B, S, H, hd).transpose(1, 2)
+    k = qkv[:, H * hd:2 * H * hd].float().view(B, S, H, hd).transpose(1, 2)
+    qe, ke = O.apply_rope(q, k, cos, sin)
+    g = qkv.cuda().clone()
+    ops.rope_inplace(g, cs, S, H, hd, 2, 1)
+    assert relerr(g[:, :H * hd].view(B, S, H, hd).transpose(1, 2), qe) < TOL
+    assert relerr(g[:, H * hd:2 * H * hd].view(B, S, H, hd).transpose(1, 2), ke) < TOL
+    assert torch.equal(g[:, 2 * H * hd:].cpu(), qkv[:, 2 * H * hd:])
+    ops.rope_inplace(g, cs, S, H, hd, 2, -1)   # inverse rotation = backward
+    assert relerr(g, qkv) < 2 * TOL
+
+
+@pytest.mark.parametrize("B,S,H,hd,causal,lens", [
+    (2, 40, 2, 128, True, [40, 29]),
+    (1, 200, 2, 128, True, None),
+    (2, 50, 2, 64, False, None),
+    (1, 577, 2, 64, False, None),
+    (2, 130, 3, 64, True, [130, 7]),
+    (1, 704, 2, 128, True, [650]),
+])
+def test_attention_fwd_bwd(ops, B, S, H, hd, causal, lens):
+    from oracle import llava_oracle as O
+    d = H * hd
+    s_pad = (S + 63) // 64 * 64
+    qkv = rnd(17, (B * S, 3 * d), 1.0)
+    dout = rnd(18, (B * S, d), 1.0)
+    if lens is not None:
+        for b, L in enumerate(lens):
+            dout.view(B, S, d)[b, L:] = 0
+    heads = lambda t: t.float().view(B, S, H, hd).transpose(1, 2)
+    q, k, v = (heads(qkv[:, i * d:(i + 1) * d]).requires_grad_(True) for i in range(3))
+    ref = O.attention(q, k, v, lens=lens, causal=causal)
+    ref.backward(heads(dout))
+    g = qkv.cuda()
+    gq, gk, gv = g[:, :d], g[:, d:2 * d], g[:, 2 * d:]
+    vT = ops.transpose_heads(gv, B, S, H, hd, s_pad)
+    lens_t = torch.tensor(lens, dtype=torch.int32, device="cuda") if lens is not None else None
+    out, lse = ops.attn_fwd(gq, gk, vT, B, S, H, hd, s_pad, causal, lens=lens_t)
+    got = out.view(B, S, H, hd).transpose(1, 2)
+    valid = torch.ones(B, S, dtype=torch.bool)
+    if lens is not None:
+        for b, L in enumerate(lens):
+            valid[b, L:] = False
+    vm = valid[:, None, :, None].expand(B, H, S, hd)
+    assert relerr(got.cpu().float()[vm], ref.detach()[vm]) < TOL
+    # lse against a direct fp32 computation
+    sc = (q.detach() @ k.detach().transpose(2, 3)) / math.sqrt(hd)
+    if causal:
+        sc = sc.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
+    if lens is not None:
+        kp = torch.arange(S)[None, :] >= torch.tensor(lens)[:, None]
+        sc = sc.masked_fill(kp[:, None, None, :], float("-inf"))
+    lse_ref = torch.logsumexp(sc, -1)
+    vl = valid[:, None, :].expand(B, H, S)
+    assert float((lse[..., :S].cpu()[vl] - lse_ref[vl]).abs().max()) < 2e-3
+    dq, dk, dv = ops.attn_bwd(gq, gk, gv, out, dout.cuda(), lse, B, S, H, hd, s_pad, causal, lens=lens_t)
+    for name, gg, rr in (("dq", dq, q.grad), ("dk", dk, k.grad), ("dv", dv, v.grad)):
+        e = relerr(gg.view(B, S, H, hd).transpose(1, 2).cpu().float()[vm], rr[vm])
+        assert e < 2 * TOL, (name, e)
+        if lens is not None:  # gradients of padded keys/queries are exactly zero
+            assert float(gg.view(B, S, H, hd).transpose(1, 2).cpu().float()[~vm].abs().max()) == 0.0, name
+
+
+def test_swiglu_gelu(ops):
+    rows, F = 37, 448
+    gu, dact = rnd(19, (rows, 2 * F)), rnd(20, (rows, F))
+    g, u = gu[:, :F].float().requires_grad_(True), gu[:, F:].float().requires_grad_(True)
+    act = torch.nn.functional.silu(g) * u
+    act.backward(dact.float())
+    a = ops.swiglu_fwd(gu.cuda(), F)
+    assert relerr(a, act) < TOL
+    dgu = ops.swiglu_bwd(dact.cuda(), gu.cuda(), F)
+    assert relerr(dgu[:, :F], g.grad) < TOL and relerr(dgu[:, F:], u.grad) < TOL
+    x, dy = rnd(21, (64, 256)), rnd(22, (64, 256))
+    xr = x.float().requires_grad_(True)
+    y = torch.nn.functional.gelu(xr)
+    y.backward(dy.float())
+    assert relerr(ops.gelu_fwd(x.cuda()), y) < TOL
+    assert relerr(ops.gelu_bwd(dy.cuda(), x.cuda()), xr.grad) < TOL
+
+
+@pytest.mark.parametrize("rows,V", [(19, 1000), (33, 32000)])
+def test_cross_entropy(ops, rows, V):
+    logits = rnd(23, (rows, V), 2.0)
+    labels = torch.from_numpy(prng.integers(11, 24, (rows,), 0, V))
+    labels[::5] = -100
+    lr = logits.float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lr, labels, ignore_index=-100)
+    ref.backward()
+    count = int((labels >= 0).sum())
+    g = logits.cuda().clone()
+    loss, rows_loss = ops.cross_entropy(g, labels.cuda(), V, 1.0 / count)
+    assert abs(float(loss) - float(ref)) < 1e-4 * max(1.0, abs(float(ref)))
+    assert relerr(g, lr.grad) < TOL
+    assert float(g.float()[labels.cuda() < 0].abs().max()) == 0.0
+
+
+def test_gather_and_segment_sum(ops):
+    d = 256
+    ta, tb = rnd(25, (50, d)).cuda(), rnd(26, (20, d)).cuda()
+    idx = torch.tensor([3, -1, -2, 49, -21, 0, -1], dtype=torch.int32, device="cuda")
+    out = ops.gather_rows(idx, d, ta, tb)
+    ref = torch.stack([ta[3], torch.zeros_like(ta[0]), tb[0], ta[49], tb[19], ta[0], torch.zeros_like(ta[0])])
+    assert torch.equal(out.cpu(), ref.cpu())
+    src = rnd(27, (30, d)).cuda()
+    seg_off = torch.tensor([0, 3, 4, 9], dtype=torch.int32, device="cuda")
+    pos = torch.tensor([1, 5, 7, 2, 10, 11, 12, 13, 29], dtype=torch.int32, device="cuda")
+    out_row = torch.tensor([4, 0, 17], dtype=torch.int32, device="cuda")
+    out = torch.zeros(20, d, dtype=torch.bfloat16, device="cuda")
+    ops.segment_sum_rows(src, seg_off, pos, out_row, out)
+    s = src.float().cpu()
+    assert relerr(out[4], s[[1, 5, 7]].sum(0)) < TOL and relerr(out[0], s[2]) < 1e-6
+    assert relerr(out[17], s[[10, 11, 12, 13, 29]].sum(0)) < TOL
+    assert float(out[1].float().abs().max()) == 0.0
+
+
+def test_clip_embeddings(ops):
+    n, H, p, d = 2, 56, 14, 128
+    pix = rnd(28, (n, 3, H, H))
+    w = rnd(29, (d, 3, p, p), 0.05)
+    cls, pos = rnd(30, (d,), 0.05), rnd(31, ((H // p) ** 2 + 1, d), 0.05)
+    ref = torch.nn.functional.conv2d(pix.float(), w.float(), stride=p).flatten(2).transpose(1, 2)
+    ref = torch.cat([cls.float().expand(n, 1, d), ref], 1) + pos.float()[None]
+    kp = (3 * p * p + 7) // 8 * 8
+    cols = ops.im2col_patches(pix.cuda(), p, kp)
+    wp = torch.zeros(d, kp, dtype=torch.bfloat16)
+    wp[:, :3 * p * p] = w.view(d, -1)
+    po = ops.gemm_nt(cols, wp.cuda())
+    emb = ops.clip_embed(po, cls.cuda(), pos.cuda(), n, (H // p) ** 2, d)
+    assert relerr(emb.view(n, -1, d), ref) < TOL
+
+
+def test_adamw_and_gradnorm(ops):
+    from oracle import llava_oracle as O
+    n = 10007
+    p0 = torch.from_numpy(prng.normal(11, 32, (n,), 0.02))
+    p = p0.clone()
+    m, v = torch.zeros(n), torch.zeros(n)
+    gp, gmaster = p0.to(torch.bfloat16).cuda(), p0.clone().cuda()
+    gm, gv = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        g = rnd(40 + step, (n,), 0.01)
+        coef = ops.grad_norm_clip_coef(g.cuda(), 0.5)
+        norm = float(g.float().norm())
+        assert abs(float(coef[0]) - norm) < 1e-4 * norm
+        c = min(1.0, 0.5 / (norm + 1e-6))
+        assert abs(float(coef[1]) - c) < 1e-5
+        O.adamw_step(p, g.float() * c, m, v, step, lr=1e-3, wd=0.1)
+        ops.adamw(gp, gmaster, g.cuda(), gm, gv, 1e-3, 0.9, 0.999, 1e-8, 0.1, step, gscale=coef[1:])
+    assert relerr(gmaster, p) < 1e-5
+    assert relerr(gm, m) < 1e-5 and relerr(gv, v) < 1e-4
+    assert torch.equal(gp.cpu(), gmaster.cpu().to(torch.bfloat16))
