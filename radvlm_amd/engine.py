@@ -1,0 +1,426 @@
+"""LlavaEngine: the MI355X-native forward/backward/optimizer of the LLaVA training step.
+
+No autograd graph and no tracing compiler: forward and backward are explicit sequences of C-ABI kernel launches
+(radvlm_amd.ops) over flat bf16 buffers, on the current HIP stream; data-parallel gradient buckets are contiguous
+slices of the flat gradient buffer, all-reduced with RCCL on a side stream while backward continues.
+
+Reference semantics followed (paths under /root/reference/finetuning/llava):
+  forward    : LlavaLlamaForCausalLM.forward model/language_model/llava_llama.py:69-120 ->
+               prepare_inputs_labels_for_multimodal model/llava_arch.py:251-555 -> HF LlamaForCausalLM
+               (text mirror model/language_model/modeling_llama.py:1083-1185, :1304-1337), CLIPVisionTower
+               model/multimodal_encoder/clip_encoder.py:46-79, mm_projector model/multimodal_projector/builder.py:41-48
+  freeze     : tower frozen (clip_encoder.py:42), projector + LM trainable (train/train.py:1613-1665)
+  optimizer  : AdamW groups of LLaVATrainer.create_optimizer train/llava_trainer.py:356-433
+  grad sync  : what DDP would do for the reference: mean over ranks of per-rank mean losses
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .params import VP, FlatParams, fast_random_init_, lm_param_shapes, portable_init_, vision_param_shapes
+from .splice import build_splice_plan, merged_feature_rows, shifted_labels
+
+BF16 = torch.bfloat16
+
+
+def _ru(x, m):
+    return (x + m - 1) // m * m
+
+
+class LlavaEngine:
+    def __init__(self, geo, device="cuda", merge_type="flat", image_aspect_ratio="square", image_grid_pinpoints=None,
+                 max_len=None, init="portable", seed=0, rms_eps=1e-5, rope_theta=10000.0, process_group=None,
+                 bucket_layers=1):
+        self.geo = geo
+        self.v, self.l = geo["vision"], geo["lm"]
+        self.device = torch.device(device)
+        self.merge_type = merge_type
+        self.aspect = image_aspect_ratio
+        self.pinpoints = image_grid_pinpoints
+        self.max_len = max_len
+        self.eps = rms_eps
+        self.theta = rope_theta
+        self.with_newline = "unpad" in merge_type
+        self.side = self.v["image"] // self.v["patch"]
+        self.P = self.side * self.side
+        self.kp = _ru(3 * self.v["patch"] ** 2, 8)
+        self.lm = FlatParams(lm_param_shapes(geo, self.with_newline), self.device)
+        self.vis = FlatParams(vision_param_shapes(geo), self.device)
+        self.grads = self.lm.like(BF16)
+        if init == "portable":
+            portable_init_(self.lm, self.l["d"], seed)
+            portable_init_(self.vis, self.l["d"], seed)
+        elif init == "fast":
+            fast_random_init_(self.lm, self.l["d"], seed)
+            fast_random_init_(self.vis, self.l["d"], seed + 1)
+        self._wT = {}
+        self._wT_valid = False
+        self._patch_w = None
+        self._rope = {}
+        self.master = self.m = self.vv = None
+        self.opt_step = 0
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.bucket_layers = bucket_layers
+        self._comm_stream = torch.cuda.Stream(device=self.device) if self.world > 1 else None
+        self._pending = []
+        self.ctx = None
+        self.grad_accum_started = False
+
+    # ------------------------------------------------------------------ weights
+    def W(self, name):
+        return self.lm.view(name)
+
+    def G(self, name):
+        return self.lm.view(name, self.grads)
+
+    def _layer_views(self, i, flat=None):
+        d, F = self.l["d"], self.l["ffn"]
+        p = f"model.layers.{i}."
+        f = self.lm
+        return dict(
+            ln1=f.view(p + "input_layernorm.weight", flat),
+            qkv=f.fused(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", 3 * d, d, flat),
+            o=f.view(p + "self_attn.o_proj.weight", flat),
+            ln2=f.view(p + "post_attention_layernorm.weight", flat),
+            gu=f.fused(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", 2 * F, d, flat),
+            down=f.view(p + "mlp.down_proj.weight", flat),
+        )
+
+    def weights_changed(self):
+        """Call after any in-place edit of the flat parameters (load_state_dict, optimizer step)."""
+        self._wT_valid = False
+        self._patch_w = None
+
+    def _refresh_transposes(self):
+        """W^T copies for the dgrad GEMMs (the GEMM kernel wants both operands contraction-contiguous)."""
+        if self._wT_valid:
+            return
+        def T(key, w):
+            N, K = w.shape
+            buf = self._wT.get(key)
+            if buf is None:
+                buf = self._wT[key] = torch.empty(K, _ru(N, 8), dtype=BF16, device=self.device)
+            ops.transpose(w, r_pad=buf.shape[1], out=buf)
+        for i in range(self.l["layers"]):
+            lv = self._layer_views(i)
+            for k in ("qkv", "o", "gu", "down"):
+                T((i, k), lv[k])
+        T("lm_head", self.W("lm_head.weight"))
+        T("proj2", self.W("model.mm_projector.2.weight"))
+        self._wT_valid = True
+
+    def rope_table(self, S):
+        if S not in self._rope:
+            self._rope[S] = ops.rope_table(S, self.l["d"] // self.l["heads"], self.theta, self.device)
+        return self._rope[S]
+
+    # ------------------------------------------------------------------ vision tower (frozen, forward only)
+    def _vision_prepare(self):
+        if self._patch_w is None:
+            w = self.vis.view(VP + "embeddings.patch_embedding.weight").reshape(self.v["d"], -1)
+            pw = torch.zeros(self.v["d"], self.kp, dtype=BF16, device=self.device)
+            pw[:, :w.shape[1]] = w
+            self._patch_w = pw
+
+    def vision_forward(self, pixels):
+        """pixels bf16 [n,3,H,W] -> hidden_states[-2] as rows [n*(P+1), dv] (clip_encoder.py:68-79, select_layer -2)."""
+        v, f = self.v, self.vis
+        self._vision_prepare()
+        n = pixels.shape[0]
+        dv, H = v["d"], v["heads"]
+        hd = dv // H
+        N = self.P + 1
+        n_pad = _ru(N, 64)
+        cols = ops.im2col_patches(pixels, v["patch"], self.kp)
+        po = ops.gemm_nt(cols, self._patch_w)
+        x = ops.clip_embed(po, f.view(VP + "embeddings.class_embedding"), f.view(VP + "embeddings.position_embedding.weight"),
+                           n, self.P, dv)
+        x = ops.layernorm_fwd(x, f.view(VP + "pre_layrnorm.weight"), f.view(VP + "pre_layrnorm.bias"))
+        for i in range(v["layers"] - 1):  # hidden_states[-2] = input of the last layer
+            p = VP + f"encoder.layers.{i}."
+            h = ops.layernorm_fwd(x, f.view(p + "layer_norm1.weight"), f.view(p + "layer_norm1.bias"))
+            wqkv = f.fused(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", 3 * dv, dv)
+            bqkv = f.fused(p + "self_attn.q_proj.bias", p + "self_attn.v_proj.bias", 1, 3 * dv).view(-1)
+            qkv = ops.gemm_nt(h, wqkv, bias=bqkv)
+            vT = ops.transpose_heads(qkv[:, 2 * dv:], n, N, H, hd, n_pad)
+            a, _ = ops.attn_fwd(qkv[:, :dv], qkv[:, dv:2 * dv], vT, n, N, H, hd, n_pad, causal=False)
+            x = ops.gemm_nt(a, f.view(p + "self_attn.out_proj.weight"), bias=f.view(p + "self_attn.out_proj.bias"), residual=x)
+            h = ops.layernorm_fwd(x, f.view(p + "layer_norm2.weight"), f.view(p + "layer_norm2.bias"))
+            h = ops.gemm_nt(h, f.view(p + "mlp.fc1.weight"), bias=f.view(p + "mlp.fc1.bias"), act=ops.ACT_QUICK_GELU)
+            x = ops.gemm_nt(h, f.view(p + "mlp.fc2.weight"), bias=f.view(p + "mlp.fc2.bias"), residual=x)
+        return x
+
+    def encode_images(self, pixels, save=None):
+        """encode_images (llava_arch.py:192-196): tower (patch features, CLS dropped) then mlp2x_gelu projector.
+        Returns the feature table [n*P + 1, d]; its last row is reserved for image_newline."""
+        n = pixels.shape[0]
+        d = self.l["d"]
+        hid = self.vision_forward(pixels)
+        drop_cls = (torch.arange(n * self.P, device=self.device, dtype=torch.int32)
+                    + torch.arange(n, device=self.device, dtype=torch.int32).repeat_interleave(self.P) + 1)
+        f0 = ops.gather_rows(drop_cls, self.v["d"], hid)
+        z1 = ops.gemm_nt(f0, self.W("model.mm_projector.0.weight"), bias=self.W("model.mm_projector.0.bias"))
+        a1 = ops.gelu_fwd(z1)
+        table = torch.empty(n * self.P + 1, d, dtype=BF16, device=self.device)
+        ops.gemm_nt(a1, self.W("model.mm_projector.2.weight"), bias=self.W("model.mm_projector.2.bias"), out=table[:n * self.P])
+        if self.with_newline:
+            table[n * self.P].copy_(self.W("model.image_newline"))
+        else:
+            table[n * self.P].zero_()
+        if save is not None:
+            save.update(f0=f0, z1=z1, a1=a1)
+        return table
+
+    # ------------------------------------------------------------------ forward
+    def plan(self, input_ids, attention_mask, labels, images, image_sizes=None):
+        """Host-side index planning (numpy); images: list of [3,H,W] or [T,3,H,W] tensors."""
+        tiles = [1 if im.ndim == 3 else im.shape[0] for im in images]
+        rows, r0 = [], 0
+        for i, t in enumerate(tiles):
+            rows.append(merged_feature_rows(r0, t, self.side, self.merge_type, self.aspect,
+                                            tuple(image_sizes[i]) if image_sizes is not None else None, self.pinpoints,
+                                            self.v["image"]))
+            r0 += t * self.P
+        ids = np.asarray(input_ids)
+        am = np.asarray(attention_mask).astype(bool) if attention_mask is not None else np.ones_like(ids, dtype=bool)
+        lab = np.asarray(labels) if labels is not None else np.full_like(ids, -100)
+        plan = build_splice_plan(ids, am, lab, rows, r0, self.max_len)
+        plan["n_feat_rows"] = r0
+        return plan
+
+    def forward(self, input_ids, attention_mask, labels, images, image_sizes=None, want_logits=False, loss_scale=1.0):
+        """One training forward. Returns loss (fp32 device tensor [1]); keeps the context for backward()."""
+        dev = self.device
+        l = self.l
+        d, F, H, V, L = l["d"], l["ffn"], l["heads"], l["vocab"], l["layers"]
+        hd = d // H
+        plan = self.plan(input_ids, attention_mask, labels, images, image_sizes)
+        pix = torch.cat([(im if im.ndim == 4 else im[None]) for im in images], 0)
+        pix = pix.to(dev, non_blocking=True)
+        pix = pix if pix.dtype == BF16 else ops.to_bf16(pix.float())
+        ctx = dict(plan=plan)
+        table = self.encode_images(pix.contiguous(), save=ctx)
+        B = len(images)
+        S = plan["S"]
+        M = B * S
+        s_pad = _ru(S, 64)
+        idx = torch.from_numpy(plan["idx"]).to(dev, non_blocking=True)
+        lens = torch.from_numpy(plan["lens"]).to(dev, non_blocking=True)
+        x = ops.gather_rows(idx, d, self.W("model.embed_tokens.weight"), table)
+        cs = self.rope_table(S)
+        layers = []
+        for i in range(L):
+            lv = self._layer_views(i)
+            h1, rstd1 = ops.rmsnorm_fwd(x, lv["ln1"], self.eps)
+            qkv = ops.gemm_nt(h1, lv["qkv"])
+            ops.rope_inplace(qkv, cs, S, H, hd, 2, 1)
+            vT = ops.transpose_heads(qkv[:, 2 * d:], B, S, H, hd, s_pad)
+            attn, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], vT, B, S, H, hd, s_pad, causal=True, lens=lens)
+            x_mid = ops.gemm_nt(attn, lv["o"], residual=x)
+            h2, rstd2 = ops.rmsnorm_fwd(x_mid, lv["ln2"], self.eps)
+            gu = ops.gemm_nt(h2, lv["gu"])
+            act = ops.swiglu_fwd(gu, F)
+            x_out = ops.gemm_nt(act, lv["down"], residual=x_mid)
+            layers.append(dict(x=x, rstd1=rstd1, h1=h1, qkv=qkv, attn=attn, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2,
+                               gu=gu, act=act))
+            x = x_out
+        hN, rstdN = ops.rmsnorm_fwd(x, self.W("model.norm.weight"), self.eps)
+        logits = ops.gemm_nt(hN, self.W("lm_head.weight"))
+        tgt = shifted_labels(plan["labels"])
+        count = int((tgt != -100).sum())
+        inv = (1.0 / count) if count > 0 else float("nan")
+        tgt_t = torch.from_numpy(tgt.reshape(-1)).to(dev, non_blocking=True)
+        logits_out = ops.to_f32(logits).view(B, S, V) if want_logits else None
+        # CE writes dlogits (scaled by loss_scale/count/world) over the logits buffer
+        gscale = loss_scale / self.world
+        loss, _ = self._cross_entropy(logits, tgt_t, V, inv, gscale)
+        ctx.update(B=B, S=S, M=M, s_pad=s_pad, lens=lens, layers=layers, x_last=x, rstdN=rstdN, hN=hN, dlogits=logits,
+                   table_rows=table.shape[0], count=count)
+        self.ctx = ctx
+        self.last_logits = logits_out
+        return loss
+
+    def _cross_entropy(self, logits, tgt, V, inv, gscale):
+        from . import lib
+        rows = logits.shape[0]
+        loss_rows = torch.empty(rows, dtype=torch.float32, device=logits.device)
+        lib.call("rv_cross_entropy", logits, logits.stride(0), tgt, loss_rows, logits, logits.stride(0), rows, V, inv * gscale)
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        lib.call("rv_sum_f32", loss_rows, rows, inv, loss)
+        return loss, loss_rows
+
+    # ------------------------------------------------------------------ backward
+    def _linear_bwd(self, dy, x, wT, gw, need_dx=True, dx_out=None):
+        """dX = dY W (via W^T copy), dW = dY^T X (via transposed activations); writes dW into the flat grad view."""
+        M = dy.shape[0]
+        mp = _ru(M, 8)
+        dyT = ops.transpose(dy, r_pad=mp)
+        xT = ops.transpose(x, r_pad=mp)
+        acc = self.grad_accum_started
+        ops.gemm_nt(dyT, xT, out=gw, residual=gw if acc else None)
+        if need_dx:
+            N = dy.shape[1]
+            return ops.gemm_nt(dy, wT[:, :N], out=dx_out)
+        return None
+
+    def backward(self):
+        """Backward of the last forward(); gradients land in self.grads (bf16, flat)."""
+        c = self.ctx
+        assert c is not None, "forward() first"
+        self._refresh_transposes()
+        l = self.l
+        d, F, H, V, L = l["d"], l["ffn"], l["heads"], l["vocab"], l["layers"]
+        hd = d // H
+        B, S, M, s_pad, lens = c["B"], c["S"], c["M"], c["s_pad"], c["lens"]
+        acc = self.grad_accum_started
+        cs = self.rope_table(S)
+        # head
+        dhN = self._linear_bwd(c["dlogits"], c["hN"], self._wT["lm_head"], self.G("lm_head.weight"))
+        dx, _ = ops.rmsnorm_bwd(dhN, c["x_last"], self.W("model.norm.weight"), c["rstdN"], dw=self.G("model.norm.weight"),
+                                dw_accumulate=acc)
+        self._bucket_done("lm_head.weight", "lm_head.weight")
+        self._bucket_done("model.norm.weight", "model.norm.weight")
+        for i in reversed(range(L)):
+            a = c["layers"][i]
+            lv, gv = self._layer_views(i), self._layer_views(i, self.grads)
+            dact = self._linear_bwd(dx, a["act"], self._wT[(i, "down")], gv["down"])
+            dgu = ops.swiglu_bwd(dact, a["gu"], F)
+            dh2 = self._linear_bwd(dgu, a["h2"], self._wT[(i, "gu")], gv["gu"])
+            ops.rmsnorm_bwd(dh2, a["x_mid"], lv["ln2"], a["rstd2"], dx=dx, dx_add=True, dw=gv["ln2"], dw_accumulate=acc)
+            dattn = self._linear_bwd(dx, a["attn"], self._wT[(i, "o")], gv["o"])
+            qkv = a["qkv"]
+            dqkv = torch.empty_like(qkv)
+            ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a["attn"], dattn, a["lse"], B, S, H, hd, s_pad, True,
+                         lens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:])
+            ops.rope_inplace(dqkv, cs, S, H, hd, 2, -1)
+            dh1 = self._linear_bwd(dqkv, a["h1"], self._wT[(i, "qkv")], gv["qkv"])
+            ops.rmsnorm_bwd(dh1, a["x"], lv["ln1"], a["rstd1"], dx=dx, dx_add=True, dw=gv["ln1"], dw_accumulate=acc)
+            c["layers"][i] = None  # free this layer's activations
+            p = f"model.layers.{i}."
+            self._bucket_done(p + "input_layernorm.weight", p + "mlp.down_proj.weight")
+        # dx = gradient of inputs_embeds [M, d]
+        plan = c["plan"]
+        dev = self.device
+        # projector: rows of dx at the positions where projector outputs were spliced in (unused rows -> zero)
+        n_rows = plan["n_feat_rows"]
+        fpos = torch.from_numpy(plan["feat_pos"]).to(dev)
+        dfeat = ops.gather_rows(fpos, d, dx)
+        g = self.G
+        ops.bias_grad(dfeat, out=g("model.mm_projector.2.bias"), accumulate=acc)
+        da1 = self._linear_bwd(dfeat, c["a1"], self._wT["proj2"], g("model.mm_projector.2.weight"))
+        dz1 = ops.gelu_bwd(da1, c["z1"])
+        ops.bias_grad(dz1, out=g("model.mm_projector.0.bias"), accumulate=acc)
+        self._linear_bwd(dz1, c["f0"], None, g("model.mm_projector.0.weight"), need_dx=False)
+        if self.with_newline:
+            gn = g("model.image_newline").view(1, d)
+            if not acc:
+                gn.zero_()
+            npos = plan["newline_pos"]
+            if npos.size:
+                tmp = torch.zeros(1, d, dtype=BF16, device=dev)
+                ops.segment_sum_rows(dx, torch.tensor([0, npos.size], dtype=torch.int32, device=dev),
+                                     torch.from_numpy(npos).to(dev), torch.zeros(1, dtype=torch.int32, device=dev), tmp)
+                gn.add_(tmp) if acc else gn.copy_(tmp)
+        # embedding rows: segment sums by token id (no atomics)
+        ge = g("model.embed_tokens.weight")
+        if acc:
+            tmp = torch.zeros_like(ge)
+            ops.segment_sum_rows(dx, torch.from_numpy(plan["tok_off"]).to(dev), torch.from_numpy(plan["tok_pos"]).to(dev),
+                                 torch.from_numpy(plan["tok_ids"]).to(dev), tmp)
+            ge.add_(tmp)
+        else:
+            ge.zero_()
+            ops.segment_sum_rows(dx, torch.from_numpy(plan["tok_off"]).to(dev), torch.from_numpy(plan["tok_pos"]).to(dev),
+                                 torch.from_numpy(plan["tok_ids"]).to(dev), ge)
+        last = "model.image_newline" if self.with_newline else "model.mm_projector.2.bias"
+        self._bucket_done("model.embed_tokens.weight", last)
+        self.ctx = None
+        self.grad_accum_started = True
+
+    # ------------------------------------------------------------------ data-parallel gradient sync
+    def _bucket_done(self, first, last):
+        """Gradients of tensors first..last are final: start their all-reduce on the comm stream (RCCL), in place."""
+        if self.world == 1 or not self.sync_this_backward:
+            return
+        s, e = self.lm.span(first, last)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._comm_stream.wait_event(ev)
+        with torch.cuda.stream(self._comm_stream):
+            w = torch.distributed.all_reduce(self.grads[s:e], group=self.pg, async_op=True)
+        self._pending.append(w)
+
+    sync_this_backward = True
+
+    def finish_grad_sync(self):
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        if self._comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+
+    def zero_grad(self):
+        self.grad_accum_started = False
+
+    # ------------------------------------------------------------------ optimizer
+    def init_optimizer(self):
+        if self.master is None:
+            self.master = ops.to_f32(self.lm.flat)
+            self.m = self.lm.like(torch.float32)
+            self.vv = self.lm.like(torch.float32)
+
+    def param_groups(self, lr, weight_decay=0.0, mm_projector_lr=None, no_decay_1d=True):
+        """Contiguous (start, end, lr, wd) slices following LLaVATrainer.create_optimizer (llava_trainer.py:369-418):
+        no weight decay for norm weights and biases; optional separate LR for the projector."""
+        groups = []
+        for name in self.lm.names():
+            off, n = self.lm.offsets[name]
+            shp = self.lm.shapes[name]
+            nodecay = no_decay_1d and (len(shp) == 1 and ("norm" in name or name.endswith("bias")))
+            glr = mm_projector_lr if (mm_projector_lr is not None and "mm_projector" in name) else lr
+            gwd = 0.0 if nodecay else weight_decay
+            if groups and groups[-1][2] == glr and groups[-1][3] == gwd and groups[-1][1] <= off:
+                groups[-1][1] = off + n  # merge (alignment gaps hold zeros and stay zero)
+            else:
+                groups.append([off, off + n, glr, gwd])
+        return [tuple(g) for g in groups]
+
+    def optimizer_step(self, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None, mm_projector_lr=None):
+        """AdamW over the flat buffers (fp32 master + moments), optional global-norm clipping without host sync."""
+        self.init_optimizer()
+        self.finish_grad_sync()
+        self.opt_step += 1
+        coef = None
+        self.last_grad_norm = None
+        if max_grad_norm is not None and max_grad_norm > 0:
+            nc = ops.grad_norm_clip_coef(self.grads, max_grad_norm)
+            self.last_grad_norm = nc[0:1]
+            coef = nc[1:2]
+        for s, e, glr, gwd in self.param_groups(lr, weight_decay, mm_projector_lr):
+            ops.adamw(self.lm.flat[s:e], self.master[s:e], self.grads[s:e], self.m[s:e], self.vv[s:e], glr, betas[0], betas[1],
+                      eps, gwd, self.opt_step, gscale=coef)
+        self.weights_changed()
+        self.zero_grad()
+
+    # ------------------------------------------------------------------ state dict (reference names)
+    def state_dict(self):
+        out = {}
+        for fp in (self.lm, self.vis):
+            for n in fp.names():
+                out[n] = fp.view(n)
+        return out
+
+    def load_state_dict(self, sd, strict=False):
+        from .params import load_named
+        m1, u1 = load_named(self.lm, sd)
+        m2, u2 = load_named(self.vis, {k: v for k, v in sd.items() if k in u1})
+        self.weights_changed()
+        if self.master is not None:
+            self.master.copy_(ops.to_f32(self.lm.flat))
+        missing, unexpected = m1 + m2, u2
+        if strict and (missing or unexpected):
+            raise KeyError(f"missing={missing[:4]} unexpected={unexpected[:4]}")
+        return missing, unexpected
