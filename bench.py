@@ -1,0 +1,213 @@
+"""bench.py -- train image-instruction pairs/s, LLaVA-1.5-7B (CLIP-ViT-L/14-336 + Vicuna-7B geometry), bf16, MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = forward + backward + gradient all-reduce (N > 1, RCCL, overlapped with backward) + AdamW update of all
+6.76 B trainable parameters, on a synthetic batch of SURVEY.md section 8d's config-2 sample (one 336x336 image,
+129 ids with the image placeholder at position 35 -> S = 704), random-init weights.  Prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TF_PER_PAIR = {"llava15_7b": 28.75, "config1": 0.089, "toy": None}  # BASELINE.md section 3 (algorithmic, ViT frozen)
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def synthetic_batch(geo, b, seed):
+    """SURVEY.md section 8d inputs: ids uniform in [3, V), IMAGE_TOKEN_INDEX at 35, first 64 text positions ignored."""
+    V = geo["lm"]["vocab"]
+    rng = np.random.default_rng(seed)
+    n_ids = 129
+    ids = rng.integers(3, V, size=(b, n_ids), dtype=np.int64)
+    labels = ids.copy()
+    labels[:, :64] = -100
+    ids[:, 35] = -200
+    labels[:, 35] = -100
+    mask = np.ones_like(ids, dtype=bool)
+    g = torch.Generator().manual_seed(seed)
+    img = geo["vision"]["image"]
+    images = [torch.randn(3, img, img, generator=g).to(torch.bfloat16) for _ in range(b)]
+    return ids, mask, labels, images
+
+
+def cpu_baseline(geo, seconds_budget=25.0):
+    """Reference CPU path (oracle, torch fp32) timed on this host's cores on a bounded sample: one decoder layer
+    fwd+bwd and one ViT layer fwd at b=1 (S=704 / 577 tokens), scaled by layer counts, + lm_head/CE fwd+bwd."""
+    from oracle import llava_oracle as O
+    import torch.nn.functional as F
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    l, v = geo["lm"], geo["vision"]
+    d, S = l["d"], 704
+    g = torch.Generator().manual_seed(0)
+    P = {}
+    pre = "model.layers.0."
+    for n, shp in (("self_attn.q_proj.weight", (d, d)), ("self_attn.k_proj.weight", (d, d)), ("self_attn.v_proj.weight", (d, d)),
+                   ("self_attn.o_proj.weight", (d, d)), ("mlp.gate_proj.weight", (l["ffn"], d)), ("mlp.up_proj.weight", (l["ffn"], d)),
+                   ("mlp.down_proj.weight", (d, l["ffn"])), ("input_layernorm.weight", (d,)), ("post_attention_layernorm.weight", (d,))):
+        P[pre + n] = (torch.randn(*shp, generator=g) * 0.02).requires_grad_(True)
+    x = torch.randn(1, S, d, generator=g).requires_grad_(True)
+    cos, sin = O.rope_cos_sin(S, d // l["heads"])
+
+    def dec():
+        y = O.decoder_layer(x, P, pre, l["heads"], [S], cos, sin)
+        y.sum().backward()
+
+    def timeit(fn, reps):
+        fn()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t) / reps
+
+    t_dec = timeit(dec, 2)
+    # ViT layer forward (frozen tower)
+    dv, N = v["d"], (v["image"] // v["patch"]) ** 2 + 1
+    vp = "model.vision_tower.vision_tower.vision_model."
+    geo1 = {"vision": dict(v, layers=2), "lm": l}
+    PV = {k: torch.randn(*shp, generator=g) * 0.02 for k, shp in O.param_shapes(geo1).items() if k.startswith(vp)}
+    pix = torch.randn(1, 3, v["image"], v["image"], generator=g)
+    with torch.no_grad():
+        t_vit = timeit(lambda: O.clip_vision_hidden(PV, geo1, pix, -2), 2)  # embeddings + 1 layer
+    # head
+    wh = (torch.randn(l["vocab"], d, generator=g) * 0.02).requires_grad_(True)
+    hN = torch.randn(1, S, d, generator=g).requires_grad_(True)
+    lab = torch.randint(0, l["vocab"], (1, S), generator=g)
+
+    def head():
+        O.causal_lm_loss(F.linear(hN, wh), lab).backward()
+
+    t_head = timeit(head, 1)
+    step = l["layers"] * t_dec + (v["layers"] - 1) * t_vit + t_head
+    return {"value": 1.0 / step, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32, b=1: 1 decoder layer fwd+bwd ({t_dec:.2f}s) x{l['layers']} + 1 ViT layer fwd ({t_vit:.2f}s) "
+                      f"x{v['layers'] - 1} + lm_head/CE fwd+bwd ({t_head:.2f}s); optimizer not included"}
+
+
+class GemmTimer:
+    """Wraps ops.gemm_nt with HIP events (on the launch stream) to get the dominant kernel's flops and time."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.orig = ops.gemm_nt
+        self.records = []
+
+    def __enter__(self):
+        def timed(a, b, *args, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self.orig(a, b, *args, **kw)
+            e1.record()
+            self.records.append((2.0 * a.shape[0] * b.shape[0] * a.shape[1], e0, e1))
+            return out
+        self.ops.gemm_nt = timed
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.gemm_nt = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        flops = sum(r[0] for r in self.records)
+        ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
+        return flops, ms, len(self.records)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="pairs per GPU per step (global batch 256 at 8 GPUs)")
+    ap.add_argument("--geometry", default="llava15_7b")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lr", type=float, default=2e-5)
+    args = ap.parse_args()
+
+    from radvlm_amd import lib, ops
+    from radvlm_amd.config import GEOMETRIES
+    from radvlm_amd.engine import LlavaEngine
+    lib.load()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    pg = None
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        pg = torch.distributed.group.WORLD
+    geo = GEOMETRIES[args.geometry]
+    eng = LlavaEngine(geo, device=f"cuda:{local}", init="fast", seed=0, process_group=pg)
+    eng.init_optimizer()
+    batch = synthetic_batch(geo, args.batch, seed=1234 + rank)
+
+    def step():
+        loss = eng.forward(*batch)
+        eng.backward()
+        eng.optimizer_step(lr=args.lr, weight_decay=0.0, max_grad_norm=1.0)
+        return loss
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=f"cuda:{local}")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    final_loss = float(loss)
+    ms_per_step = dt / args.steps * 1e3
+    pairs = args.batch * world * args.steps
+    value = pairs / dt
+
+    # dominant kernel (bf16 MFMA GEMM): algorithmic flops / measured launch time, one extra instrumented step
+    with GemmTimer(ops) as gt:
+        step()
+        gflops, gms, nlaunch = gt.summary()
+    roofline = {"bound": "mfma", "kernel": "gemm_nt_kernel", "achieved": gflops / (gms * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s", "traffic": None, "launches_per_step": nlaunch, "gemm_ms_per_step": gms}
+    roofline["frac"] = roofline["achieved"] / roofline["peak"]
+    tf_pair = TF_PER_PAIR.get(args.geometry)
+    if tf_pair:
+        roofline["step_algorithmic_tflops"] = tf_pair * args.batch / (ms_per_step * 1e-3)
+        roofline["step_frac_of_mfma_peak"] = roofline["step_algorithmic_tflops"] / PEAK_BF16_TFLOPS
+    if rank == 0:
+        out = {
+            "metric": "train image-instruction pairs/sec, LLaVA-1.5-7B 336px", "value": value, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.geometry} full fine-tune step (ViT frozen): fwd+bwd+AdamW, S=704, "
+                                   f"{args.batch} pairs/GPU/step", "global_batch": args.batch * world, "seq_len": 704,
+                       "parallelism": f"dp{world}", "final_loss": final_loss},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(geo)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
