@@ -1,0 +1,208 @@
+"""``LlavaConfig`` / ``LlavaLlamaModel`` / ``LlavaLlamaForCausalLM`` over the MI355X engine.
+
+Mirrors the boundary class of reference finetuning/llava/model/language_model/llava_llama.py:35-156 and the
+LlavaMetaModel / LlavaMetaForCausalLM glue of model/llava_arch.py:36-124, 192-196, 251-555:
+same ``forward`` keyword list, ``.loss`` (fp32 scalar, mean CE over non-ignored shifted labels) and ``.logits``
+(fp32 [b,S,V]) on the output, ``get_model()``, ``get_vision_tower()``, ``initialize_vision_modules`` and
+``initialize_vision_tokenizer``, reference state-dict names.  ``out.loss.backward()`` runs the engine's hand-written
+backward (one autograd node for the whole step), so an HF-Trainer-style ``training_step`` drives it unchanged.
+"""
+import os
+from types import SimpleNamespace
+
+import torch
+
+from ...engine import LlavaEngine
+
+
+class LlavaConfig:
+    model_type = "llava_llama"
+
+    def __init__(self, geometry=None, mm_patch_merge_type="flat", image_aspect_ratio="square", image_grid_pinpoints=None,
+                 tokenizer_model_max_length=None, rms_norm_eps=1e-5, rope_theta=10000.0, **kw):
+        from ...config import GEOMETRIES
+        self.geometry = geometry or GEOMETRIES["llava15_7b"]
+        l, v = self.geometry["lm"], self.geometry["vision"]
+        self.hidden_size, self.intermediate_size = l["d"], l["ffn"]
+        self.num_hidden_layers, self.num_attention_heads, self.num_key_value_heads = l["layers"], l["heads"], l["heads"]
+        self.vocab_size = l["vocab"]
+        self.rms_norm_eps, self.rope_theta = rms_norm_eps, rope_theta
+        self.mm_hidden_size = v["d"]
+        self.mm_projector_type = "mlp2x_gelu"
+        self.mm_vision_select_layer = -2
+        self.mm_vision_select_feature = "patch"
+        self.mm_patch_merge_type = mm_patch_merge_type
+        self.image_aspect_ratio = image_aspect_ratio
+        self.image_grid_pinpoints = image_grid_pinpoints
+        self.tokenizer_model_max_length = tokenizer_model_max_length
+        self.tokenizer_padding_side = "right"
+        self.use_cache = False
+        self.use_mm_proj = True
+        for k, val in kw.items():
+            setattr(self, k, val)
+
+
+class CausalLMOutputWithPast(SimpleNamespace):
+    def __getitem__(self, i):
+        return (self.loss, self.logits)[i]
+
+
+class _StepFunction(torch.autograd.Function):
+    """One autograd node for the whole training step: forward saved its context inside the engine."""
+
+    @staticmethod
+    def forward(ctx, flat_params, engine, loss):
+        ctx.engine = engine
+        return loss.clone().view(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        eng = ctx.engine
+        # d(loss)/d(params) is accumulated into engine.grads by the hand-written backward; the incoming scalar
+        # multiplier (1 for plain loss.backward()) must be 1 -- loss scaling goes through forward(loss_scale=...).
+        eng.backward()
+        return None, None, None
+
+
+class CLIPVisionTower:
+    """Handle with the attributes the reference reads off its tower (clip_encoder.py:81-122)."""
+
+    def __init__(self, engine):
+        self._e = engine
+        self.is_loaded = True
+        self.select_layer, self.select_feature = -2, "patch"
+
+    @property
+    def config(self):
+        v = self._e.v
+        return SimpleNamespace(hidden_size=v["d"], image_size=v["image"], patch_size=v["patch"], num_hidden_layers=v["layers"])
+
+    hidden_size = property(lambda s: s._e.v["d"])
+    image_size = property(lambda s: s._e.v["image"])
+    num_patches_per_side = property(lambda s: s._e.side)
+    num_patches = property(lambda s: s._e.P)
+    dtype = torch.bfloat16
+    device = property(lambda s: s._e.device)
+
+    def load_model(self, device_map=None):
+        return None
+
+    def __call__(self, images):
+        """[n,3,H,W] -> [n,P,dv] patch features of hidden_states[-2] (clip_encoder.py:68-79)."""
+        from ... import ops
+        e = self._e
+        x = images.to(e.device)
+        x = x if x.dtype == torch.bfloat16 else ops.to_bf16(x.float())
+        h = e.vision_forward(x.contiguous()).view(x.shape[0], e.P + 1, e.v["d"])
+        return h[:, 1:]
+
+
+class LlavaLlamaModel:
+    def __init__(self, engine, config):
+        self.engine, self.config = engine, config
+        self.vision_tower = CLIPVisionTower(engine)
+
+    def get_vision_tower(self):
+        return self.vision_tower
+
+    @property
+    def embed_tokens(self):
+        return self.engine.W("model.embed_tokens.weight")
+
+    @property
+    def mm_projector(self):
+        e = self.engine
+        return {n: e.W(f"model.mm_projector.{n}") for n in ("0.weight", "0.bias", "2.weight", "2.bias")}
+
+    def initialize_vision_modules(self, model_args, fsdp=None):
+        """Record the mm_* settings on the config (llava_arch.py:54-124); the tower/projector already live in the engine."""
+        c = self.config
+        c.mm_vision_tower = getattr(model_args, "vision_tower", None)
+        c.mm_projector_type = getattr(model_args, "mm_projector_type", "mlp2x_gelu") or "mlp2x_gelu"
+        if c.mm_projector_type not in ("mlp2x_gelu",):
+            raise NotImplementedError(f"mm_projector_type={c.mm_projector_type}: only mlp2x_gelu is on the hot path")
+        c.mm_vision_select_layer = getattr(model_args, "mm_vision_select_layer", -2)
+        if c.mm_vision_select_layer != -2:
+            raise NotImplementedError("mm_vision_select_layer must be -2 (LLaVA-1.5)")
+        c.mm_vision_select_feature = getattr(model_args, "mm_vision_select_feature", "patch")
+        c.mm_patch_merge_type = getattr(model_args, "mm_patch_merge_type", c.mm_patch_merge_type)
+        p = getattr(model_args, "pretrain_mm_mlp_adapter", None)
+        if p:
+            w = torch.load(p, map_location="cpu", weights_only=True)
+            self.engine.load_state_dict({("model." + k if not k.startswith("model.") else k): v for k, v in w.items() if "mm_projector" in k})
+
+
+class LlavaLlamaForCausalLM:
+    config_class = LlavaConfig
+
+    def __init__(self, config, device="cuda", process_group=None, init="portable", seed=0):
+        self.config = config
+        self.engine = LlavaEngine(config.geometry, device=device, merge_type=config.mm_patch_merge_type,
+                                  image_aspect_ratio=config.image_aspect_ratio, image_grid_pinpoints=config.image_grid_pinpoints,
+                                  max_len=config.tokenizer_model_max_length, init=init, seed=seed, rms_eps=config.rms_norm_eps,
+                                  rope_theta=config.rope_theta, process_group=process_group)
+        self.model = LlavaLlamaModel(self.engine, config)
+        self.training = True
+        # a leaf that makes loss require grad so that `.backward()` reaches the engine
+        self._anchor = torch.zeros(1, device=self.engine.device, requires_grad=True)
+
+    def get_model(self):
+        return self.model
+
+    def get_vision_tower(self):
+        return self.model.get_vision_tower()
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def parameters(self):
+        return [self.engine.lm.flat]
+
+    def state_dict(self):
+        return self.engine.state_dict()
+
+    def load_state_dict(self, sd, strict=False):
+        return self.engine.load_state_dict(sd, strict=strict)
+
+    def encode_images(self, images):
+        e = self.engine
+        from ... import ops
+        x = images.to(e.device)
+        x = x if x.dtype == torch.bfloat16 else ops.to_bf16(x.float())
+        return e.encode_images(x.contiguous())[:-1].view(x.shape[0], e.P, e.l["d"])
+
+    def initialize_vision_tokenizer(self, model_args, tokenizer):
+        """llava_arch.py:557-597: only the no-extra-token configuration of LLaVA-1.5 is on the hot path."""
+        if getattr(model_args, "mm_use_im_start_end", False):
+            raise NotImplementedError("mm_use_im_start_end adds trainable token rows; outside the hot path")
+
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None, labels=None,
+                use_cache=None, output_attentions=None, output_hidden_states=None, images=None, image_sizes=None, return_dict=None,
+                modalities=("image",), dpo_forward=None, cache_position=None, output_logits=None):
+        if inputs_embeds is not None or past_key_values is not None or dpo_forward:
+            raise NotImplementedError("only the training call form (input_ids + images + labels) is on the hot path")
+        if images is None:
+            raise ValueError("images is required (text-only samples carry a dummy zero image, train.py:1227-1232)")
+        imgs = list(images) if not torch.is_tensor(images) else [im for im in images]
+        ids = input_ids.cpu().numpy() if torch.is_tensor(input_ids) else input_ids
+        am = attention_mask.cpu().numpy() if torch.is_tensor(attention_mask) else attention_mask
+        lab = labels.cpu().numpy() if torch.is_tensor(labels) else labels
+        want_logits = (not self.training) if output_logits is None else output_logits
+        loss = self.engine.forward(ids, am, lab, imgs, image_sizes=image_sizes, want_logits=want_logits)
+        if self.training and labels is not None:
+            loss = _StepFunction.apply(self._anchor, self.engine, loss)
+        else:
+            self.engine.ctx = None
+        return CausalLMOutputWithPast(loss=loss if labels is not None else None, logits=self.engine.last_logits)
+
+    __call__ = forward
+
+    def save_pretrained(self, out_dir):
+        from safetensors.torch import save_file
+        os.makedirs(out_dir, exist_ok=True)
+        sd = {k: v.detach().clone().contiguous().cpu() for k, v in self.engine.state_dict().items()}
+        save_file(sd, os.path.join(out_dir, "model.safetensors"))

@@ -1,0 +1,521 @@
+"""Entry point + host data path of LLaVA fine-tuning on the MI355X engine.
+
+Mirrors the surface of reference finetuning/llava/train/train.py: the three argument groups
+(:58-166), preprocess_multimodal (:378-403), preprocess_v1 (:722-798), preprocess_plain (:882-901),
+preprocess_qwen (:560-633, ChatML masking), preprocess (:904-952), LazySupervisedDataset (:955-1239),
+DataCollatorForSupervisedDataset (:1243-1286), make_supervised_data_module (:1289-1293), find_all_linear_names
+(:242-255), the tunable-parts policy (:1613-1665) and train() (:1449-1725).  Flags that configure machinery this
+build replaces (DeepSpeed, torch.compile, bits/quantisation, gradient checkpointing) are accepted and ignored.
+"""
+import argparse
+import copy
+import dataclasses
+import json
+import math
+import os
+import random
+import re
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import torch
+from PIL import Image
+from torch.utils.data import Dataset
+
+from .. import conversation as conversation_lib
+from ..constants import DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN, DEFAULT_IMAGE_TOKEN, IGNORE_INDEX, IMAGE_TOKEN_INDEX
+from ..mm_utils import ClipImageProcessor, expand2square, process_anyres_image, tokenizer_image_token
+from .llava_trainer import LLaVATrainer
+
+
+@dataclass
+class ModelArguments:
+    model_name_or_path: Optional[str] = "facebook/opt-125m"
+    model_class_name: Optional[str] = None
+    mm_tunable_parts: Optional[str] = None
+    version: Optional[str] = "v0"
+    freeze_backbone: bool = False
+    tune_mm_mlp_adapter: bool = False
+    tune_mm_vision_resampler: bool = False
+    vision_tower: Optional[str] = None
+    vision_tower_pretrained: Optional[str] = None
+    unfreeze_mm_vision_tower: bool = False
+    unfreeze_language_model: bool = False
+    mm_vision_select_layer: Optional[int] = -1
+    pretrain_mm_mlp_adapter: Optional[str] = None
+    mm_projector_type: Optional[str] = "linear"
+    mm_use_im_start_end: bool = False
+    mm_use_im_patch_token: bool = True
+    mm_patch_merge_type: Optional[str] = "flat"
+    mm_vision_select_feature: Optional[str] = "patch"
+    mm_resampler_type: Optional[str] = None
+    mm_spatial_pool_stride: Optional[int] = None
+    mm_spatial_pool_mode: str = "bilinear"
+    rope_scaling_factor: Optional[float] = None
+    rope_scaling_type: Optional[str] = None
+    use_pos_skipping: Optional[bool] = False
+    pos_skipping_range: Optional[int] = 4096
+    mm_newline_position: Optional[str] = "grid"
+    delay_load: Optional[bool] = True
+    add_faster_video: Optional[bool] = False
+    faster_token_stride: Optional[int] = 10
+    geometry: Optional[str] = None  # build-specific: named geometry of radvlm_amd.config.GEOMETRIES (random init)
+
+
+@dataclass
+class DataArguments:
+    data_path: Optional[str] = None
+    lazy_preprocess: bool = False
+    is_multimodal: bool = False
+    early_mix_text: bool = False
+    image_folder: Optional[str] = None
+    image_aspect_ratio: str = "square"
+    image_grid_pinpoints: Optional[str] = None
+    image_crop_resolution: Optional[int] = None
+    image_split_resolution: Optional[int] = None
+    video_folder: Optional[str] = None
+    video_fps: Optional[int] = 1
+    frames_upbound: Optional[int] = 0
+    add_time_instruction: Optional[bool] = False
+    force_sample: Optional[bool] = False
+
+
+@dataclass
+class TrainingArguments:
+    """The subset of transformers.TrainingArguments the reference script uses (finetune_radio_7b.sh:45-89) plus the
+    reference's own additions (train.py:137-166)."""
+    output_dir: str = "./checkpoints"
+    cache_dir: Optional[str] = None
+    optim: str = "adamw_torch"
+    remove_unused_columns: bool = False
+    freeze_mm_mlp_adapter: bool = False
+    freeze_mm_vision_resampler: bool = False
+    model_max_length: int = 4096
+    bits: int = 16
+    double_quant: bool = True
+    quant_type: str = "nf4"
+    lora_enable: bool = False
+    lora_r: int = 64
+    lora_alpha: int = 16
+    lora_dropout: float = 0.05
+    lora_weight_path: str = ""
+    lora_bias: str = "none"
+    mm_projector_lr: Optional[float] = None
+    mm_vision_tower_lr: Optional[float] = None
+    group_by_length: bool = False
+    group_by_varlen: bool = False
+    group_by_modality_length: bool = False
+    group_by_modality_length_auto: bool = False
+    gradient_checkpointing: bool = True
+    verbose_logging: bool = False
+    attn_implementation: str = "flash_attention_2"
+    bf16: bool = True
+    tf32: bool = True
+    fp16: bool = False
+    num_train_epochs: float = 1.0
+    max_steps: int = -1
+    per_device_train_batch_size: int = 1
+    per_device_eval_batch_size: int = 1
+    gradient_accumulation_steps: int = 1
+    learning_rate: float = 2e-5
+    weight_decay: float = 0.0
+    adam_beta1: float = 0.9
+    adam_beta2: float = 0.999
+    adam_epsilon: float = 1e-8
+    max_grad_norm: float = 1.0
+    warmup_ratio: float = 0.03
+    warmup_steps: int = 0
+    lr_scheduler_type: str = "cosine"
+    logging_steps: int = 1
+    save_strategy: str = "steps"
+    save_steps: int = 500
+    save_total_limit: Optional[int] = None
+    evaluation_strategy: str = "no"
+    dataloader_num_workers: int = 4
+    dataloader_drop_last: bool = False
+    report_to: str = "none"
+    run_name: Optional[str] = None
+    seed: int = 42
+    deepspeed: Optional[str] = None      # accepted, ignored: ZeRO-3 sharding is replaced by plain DP
+    torch_compile: bool = False          # accepted, ignored
+    torch_compile_backend: Optional[str] = None
+    local_rank: int = -1
+    world_size: int = 1
+    process_index: int = 0
+
+
+def parse_args_into_dataclasses(argv=None):
+    """HfArgumentParser-style CLI: every dataclass field is a --flag; unknown flags are an error like the reference."""
+    groups = (ModelArguments, DataArguments, TrainingArguments)
+    ap = argparse.ArgumentParser()
+    for g in groups:
+        for f in dataclasses.fields(g):
+            t = f.type
+            base = str(t)
+            if "bool" in base:
+                ap.add_argument(f"--{f.name}", type=lambda s: str(s).lower() in ("1", "true", "yes"), nargs="?", const=True, default=f.default)
+            elif "int" in base and "float" not in base:
+                ap.add_argument(f"--{f.name}", type=int, default=f.default)
+            elif "float" in base:
+                ap.add_argument(f"--{f.name}", type=float, default=f.default)
+            else:
+                ap.add_argument(f"--{f.name}", type=str, default=f.default)
+    ns = vars(ap.parse_args(argv))
+    return tuple(g(**{f.name: ns[f.name] for f in dataclasses.fields(g)}) for g in groups)
+
+
+def find_all_linear_names(model):
+    """LoRA targets: every LM linear except lm_head and the multimodal modules (train.py:242-255)."""
+    skip = ("mm_projector", "vision_tower", "vision_resampler")
+    names = set()
+    for name in model.engine.lm.names():
+        if any(k in name for k in skip) or not name.endswith("_proj.weight"):
+            continue
+        names.add(name.split(".")[-2])
+    names.discard("lm_head")
+    return sorted(names)
+
+
+# ---------------------------------------------------------------------------------------------- preprocessing
+def preprocess_multimodal(sources, data_args):
+    """Move a single '<image>' to the front of its turn as '<image>\\n...' (train.py:378-403)."""
+    if not data_args.is_multimodal:
+        return sources
+    for source in sources:
+        for s in source:
+            v = s["value"]
+            if len(re.findall(DEFAULT_IMAGE_TOKEN, v)) == 1 and not v.startswith(DEFAULT_IMAGE_TOKEN):
+                v = (DEFAULT_IMAGE_TOKEN + "\n" + v.replace(DEFAULT_IMAGE_TOKEN, "").strip()).strip()
+            if getattr(data_args, "mm_use_im_start_end", False):
+                v = v.replace(DEFAULT_IMAGE_TOKEN, DEFAULT_IM_START_TOKEN + DEFAULT_IMAGE_TOKEN + DEFAULT_IM_END_TOKEN)
+            s["value"] = v.replace("QA_GT_caption_based_noisy", "")
+    return sources
+
+
+def _tok_len(text, tokenizer, has_image):
+    return len(tokenizer_image_token(text, tokenizer)) if has_image else len(tokenizer(text).input_ids)
+
+
+def preprocess_v1(sources, tokenizer, has_image=False):
+    """Vicuna-v1 template; loss only on assistant replies (instruction spans and BOS masked)."""
+    conv = conversation_lib.default_conversation.copy()
+    roles = {"human": conv.roles[0], "gpt": conv.roles[1]}
+    prompts = []
+    for source in sources:
+        if roles[source[0]["from"]] != conv.roles[0]:
+            source = source[1:]
+        conv.messages = []
+        for j, s in enumerate(source):
+            assert roles[s["from"]] == conv.roles[j % 2]
+            conv.append_message(roles[s["from"]], s["value"])
+        prompts.append(conv.get_prompt())
+    if has_image:
+        input_ids = torch.stack([tokenizer_image_token(p, tokenizer, return_tensors="pt") for p in prompts], 0)
+    else:
+        input_ids = tokenizer(prompts, return_tensors="pt", padding="longest", max_length=tokenizer.model_max_length, truncation=True).input_ids
+    targets = input_ids.clone()
+    assert conv.sep_style == conversation_lib.SeparatorStyle.TWO
+    sep = conv.sep + conv.roles[1] + ": "
+    shrink = (not getattr(tokenizer, "legacy", True))
+    for prompt, target in zip(prompts, targets):
+        total = int(target.ne(tokenizer.pad_token_id).sum())
+        cur = 1
+        target[:cur] = IGNORE_INDEX
+        for i, rnd in enumerate(prompt.split(conv.sep2)):
+            if rnd == "":
+                break
+            parts = rnd.split(sep)
+            if len(parts) != 2:
+                break
+            round_len = _tok_len(rnd, tokenizer, has_image)
+            instr_len = _tok_len(parts[0] + sep, tokenizer, has_image) - 2
+            if i != 0 and shrink:
+                round_len -= 1
+                instr_len -= 1
+            target[cur:cur + instr_len] = IGNORE_INDEX
+            cur += round_len
+        target[cur:] = IGNORE_INDEX
+        if cur < tokenizer.model_max_length and cur != total:
+            target[:] = IGNORE_INDEX
+            print(f"WARNING: tokenization mismatch: {cur} vs. {total}. (ignored)")
+    return dict(input_ids=input_ids, labels=targets)
+
+
+def preprocess_plain(sources, tokenizer):
+    """Pretraining template: '<image>' + caption + sep; the image token is masked."""
+    prompts = []
+    for source in sources:
+        assert len(source) == 2 and DEFAULT_IMAGE_TOKEN in source[0]["value"]
+        source[0]["value"] = DEFAULT_IMAGE_TOKEN
+        prompts.append(source[0]["value"] + source[1]["value"] + conversation_lib.default_conversation.sep)
+    input_ids = [tokenizer_image_token(p, tokenizer, return_tensors="pt") for p in prompts]
+    targets = copy.deepcopy(input_ids)
+    for t, source in zip(targets, sources):
+        t[:len(tokenizer_image_token(source[0]["value"], tokenizer))] = IGNORE_INDEX
+    return dict(input_ids=input_ids, labels=targets)
+
+
+def preprocess_qwen(sources, tokenizer, has_image=False, max_len=2048, system_message="You are a helpful assistant."):
+    """ChatML template via the tokenizer's chat template; non-assistant turns masked (train.py:560-633)."""
+    roles = {"human": "user", "gpt": "assistant"}
+    tokenizer = copy.deepcopy(tokenizer)
+    if has_image:
+        tokenizer.add_tokens(["<image>"], special_tokens=True)
+    image_token_index = tokenizer.convert_tokens_to_ids("<image>")
+    unmask = {tokenizer.convert_tokens_to_ids(t) for t in ("<|im_start|>", "<|im_end|>")} | set(tokenizer("\n").input_ids)
+    tokenizer.chat_template = ("{% for message in messages %}{{'<|im_start|>' + message['role'] + '\n' + message['content'] + "
+                               "'<|im_end|>' + '\n'}}{% endfor %}{% if add_generation_prompt %}{{ '<|im_start|>assistant\n' }}{% endif %}")
+    all_ids, all_tgt = [], []
+    for source in sources:
+        if roles.get(source[0]["from"], source[0]["from"]) != "user":
+            source = source[1:]
+        ids = list(tokenizer.apply_chat_template([{"role": "system", "content": system_message}]))
+        tgt = [IGNORE_INDEX] * len(ids)
+        for conv in source:
+            role = roles.get(conv.get("from", conv.get("role")), conv.get("from", conv.get("role")))
+            enc = tokenizer.apply_chat_template([{"role": role, "content": conv.get("value", conv.get("content"))}])
+            ids += enc
+            tgt += [IGNORE_INDEX] * len(enc) if role in ("user", "system") else enc
+        assert len(ids) == len(tgt)
+        for i, e in enumerate(ids):
+            if e in unmask:
+                tgt[i] = e
+            if e == image_token_index:
+                ids[i] = IMAGE_TOKEN_INDEX
+        all_ids.append(ids)
+        all_tgt.append(tgt)
+    return dict(input_ids=torch.tensor(all_ids, dtype=torch.long), labels=torch.tensor(all_tgt, dtype=torch.long))
+
+
+def preprocess(sources, tokenizer, has_image=False):
+    conv = conversation_lib.default_conversation
+    if conv.sep_style == conversation_lib.SeparatorStyle.PLAIN:
+        return preprocess_plain(sources, tokenizer)
+    if conv.version.startswith("v1"):
+        return preprocess_v1(sources, tokenizer, has_image=has_image)
+    if conv.version == "qwen":
+        return preprocess_qwen(sources, tokenizer, has_image=has_image)
+    raise NotImplementedError(f"conversation version {conv.version!r} is outside the hot path (SURVEY.md section 8)")
+
+
+# ---------------------------------------------------------------------------------------------- dataset + collator
+def _load_records(data_path, data_args):
+    """json | brace-glob '/p/{a,b}.json' | yaml {datasets: [{json_path, sampling_strategy}]} (train.py:961-1030)."""
+    def read(p):
+        with open(p) as f:
+            return [json.loads(l) for l in f] if p.endswith(".jsonl") else json.load(f)
+    m = re.match(r"^(.*)\{(.*)\}\.json$", data_path) if ("{" in data_path and "}" in data_path) else None
+    if m:
+        paths = [f"{m.group(1)}{n}.json" for n in m.group(2).split(",")]
+        data_args.dataset_paths = paths
+        return [r for p in paths for r in read(p)]
+    if data_path.endswith(".yaml"):
+        import yaml
+        with open(data_path) as f:
+            sets = yaml.safe_load(f).get("datasets")
+        data_args.dataset_paths = [d.get("json_path") for d in sets]
+        out = []
+        for d in sets:
+            cur = read(d["json_path"])
+            strat, num = d.get("sampling_strategy", "all"), None
+            if ":" in strat:
+                strat, num = strat.split(":")
+                num = math.ceil(int(num.split("%")[0]) * len(cur) / 100) if "%" in num else int(num)
+            if num is not None:
+                if strat == "first":
+                    cur = cur[:num]
+                elif strat == "end":
+                    cur = cur[-num:]
+                elif strat == "random":
+                    random.shuffle(cur)
+                    cur = cur[:num]
+            out.extend(cur)
+        return out
+    data_args.dataset_paths = [data_path]
+    return read(data_path)
+
+
+class LazySupervisedDataset(Dataset):
+    """LLaVA-format records {image?, conversations:[{from,value}], id} -> {input_ids, labels, image:[(tensor,size,modality)], id}."""
+
+    def __init__(self, data_path, tokenizer, data_args):
+        self.tokenizer, self.data_args = tokenizer, data_args
+        self.list_data_dict = _load_records(data_path, data_args)
+
+    def __len__(self):
+        return len(self.list_data_dict)
+
+    @staticmethod
+    def _words(sample):
+        return sum(len(c["value"].split()) for c in sample["conversations"])
+
+    @property
+    def lengths(self):
+        return [self._words(s) + (128 if "image" in s else 0) for s in self.list_data_dict]
+
+    @property
+    def modality_lengths(self):
+        out = []
+        for s in self.list_data_dict:
+            n = self._words(s)
+            assert n > 0, f"Conversation length is 0 for {s}"
+            out.append(n if ("image" in s or "video" in s or self.data_args.early_mix_text) else -n)
+        return out
+
+    def process_image(self, image_file, overwrite_image_aspect_ratio=None):
+        proc = self.data_args.image_processor
+        image = Image.open(os.path.join(self.data_args.image_folder or "", image_file)).convert("RGB")
+        size = image.size
+        aspect = overwrite_image_aspect_ratio or self.data_args.image_aspect_ratio
+        if aspect == "anyres" or "anyres_max" in aspect:
+            t = process_anyres_image(image, proc, self.data_args.image_grid_pinpoints)
+        elif aspect == "pad":
+            t = proc.preprocess(expand2square(image, tuple(int(x * 255) for x in proc.image_mean)), return_tensors="pt")["pixel_values"][0]
+        elif aspect in ("highres", "crop_split"):
+            raise NotImplementedError(aspect)
+        else:
+            t = proc.preprocess(image, return_tensors="pt")["pixel_values"][0]
+        return t, size, "image"
+
+    def __getitem__(self, i):
+        """Retry policy of the reference (train.py:1101-1132): 3 tries (1 s apart), 3 tries on the next sample, then raise."""
+        for _ in range(3):
+            try:
+                return self._get_item(i)
+            except Exception as e:  # noqa: BLE001
+                print(f"Failed to fetch sample {i}. Exception:", e)
+                time.sleep(1)
+        nxt = min(i + 1, len(self.list_data_dict) - 1)
+        for _ in range(3):
+            try:
+                return self._get_item(nxt)
+            except Exception as e:  # noqa: BLE001
+                print(f"Failed to fetch sample {nxt}. Exception:", e)
+        return self._get_item(i)
+
+    def _get_item(self, i):
+        rec = self.list_data_dict[i]
+        image = None
+        if "image" in rec:
+            f = rec["image"]
+            if isinstance(f, list):
+                image = [self.process_image(x, "pad" if len(f) > 1 else None) for x in f]
+            else:
+                image = [self.process_image(f)]
+            sources = preprocess_multimodal(copy.deepcopy([rec["conversations"]]), self.data_args)
+        else:
+            sources = copy.deepcopy([rec["conversations"]])
+        d = preprocess(sources, self.tokenizer, has_image="image" in rec)
+        out = dict(input_ids=d["input_ids"][0], labels=d["labels"][0])
+        if image is not None:
+            out["image"] = image
+        elif self.data_args.is_multimodal:
+            cs = self.data_args.image_processor.crop_size
+            out["image"] = [(torch.zeros(1, 3, cs["height"], cs["width"]), (cs["width"], cs["height"]), "text")]
+        out["id"] = rec.get("id", i)
+        return out
+
+
+@dataclass
+class DataCollatorForSupervisedDataset:
+    tokenizer: object
+
+    def _pad(self, seqs, value):
+        left = getattr(self.tokenizer, "padding_side", "right") == "left"
+        n = max(s.shape[0] for s in seqs)
+        out = torch.full((len(seqs), n), value, dtype=seqs[0].dtype)
+        for r, s in enumerate(seqs):
+            if left:
+                out[r, n - s.shape[0]:] = s
+            else:
+                out[r, :s.shape[0]] = s
+        return out
+
+    def __call__(self, instances: Sequence[Dict]) -> Dict:
+        L = self.tokenizer.model_max_length
+        ids = [x["input_ids"][:L] for x in instances]
+        labs = [x["labels"][:L] for x in instances]
+        if self.tokenizer.pad_token_id is None:
+            self.tokenizer.pad_token_id = 0
+        input_ids = self._pad(ids, self.tokenizer.pad_token_id)
+        labels = self._pad(labs, IGNORE_INDEX).long()
+        batch = dict(input_ids=input_ids, labels=labels, attention_mask=input_ids.ne(self.tokenizer.pad_token_id))
+        if "image" in instances[0]:
+            flat = [im for x in instances for im in x["image"]]
+            batch["image_sizes"] = [im[1] for im in flat]
+            batch["modalities"] = [im[2] for im in flat]
+            batch["images"] = [im[0] for im in flat]
+        if "prompt" in instances[0]:
+            batch["prompts"] = [x["prompt"] for x in instances]
+        return batch
+
+
+def make_supervised_data_module(tokenizer, data_args):
+    ds = LazySupervisedDataset(tokenizer=tokenizer, data_path=data_args.data_path, data_args=data_args)
+    return dict(train_dataset=ds, eval_dataset=None, data_collator=DataCollatorForSupervisedDataset(tokenizer=tokenizer))
+
+
+# ---------------------------------------------------------------------------------------------- train()
+def tunable_parts(model_args):
+    """Which parts receive gradients (train.py:1613-1665). Returns a set of {'mm_mlp_adapter','mm_language_model',
+    'mm_vision_tower'}; default (mm_tunable_parts unset, nothing frozen) = projector + language model."""
+    if model_args.mm_tunable_parts:
+        return {p.strip() for p in model_args.mm_tunable_parts.split(",")}
+    parts = {"mm_mlp_adapter", "mm_language_model"}
+    if model_args.tune_mm_mlp_adapter:
+        parts = {"mm_mlp_adapter"}
+    if model_args.freeze_backbone:
+        parts.discard("mm_language_model")
+    if model_args.unfreeze_mm_vision_tower:
+        parts.add("mm_vision_tower")
+    return parts
+
+
+def train(attn_implementation=None, argv=None, tokenizer=None):
+    from ..model import LlavaConfig, LlavaLlamaForCausalLM
+    from ...config import GEOMETRIES
+    model_args, data_args, training_args = parse_args_into_dataclasses(argv)
+    world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
+    training_args.world_size, training_args.process_index, training_args.local_rank = world, rank, local
+    torch.cuda.set_device(local)
+    pg = None
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        pg = torch.distributed.group.WORLD
+    parts = tunable_parts(model_args)
+    if "mm_vision_tower" in parts:
+        raise NotImplementedError("vision-tower fine-tuning (tower backward) is not built yet; tower is frozen")
+    if training_args.lora_enable:
+        raise NotImplementedError("LoRA (BASELINE config 5) is scheduled after the full fine-tune path (SURVEY 8f)")
+    name = model_args.geometry or ("llava15_13b" if "13b" in (model_args.model_name_or_path or "").lower() else "llava15_7b")
+    cfg = LlavaConfig(geometry=GEOMETRIES[name], mm_patch_merge_type=model_args.mm_patch_merge_type,
+                      image_aspect_ratio=data_args.image_aspect_ratio, image_grid_pinpoints=data_args.image_grid_pinpoints,
+                      tokenizer_model_max_length=training_args.model_max_length)
+    model = LlavaLlamaForCausalLM(cfg, device=f"cuda:{local}", process_group=pg, init="fast")
+    model.config.use_cache = False
+    model.get_model().initialize_vision_modules(model_args)
+    if model_args.version in conversation_lib.conv_templates:
+        conversation_lib.default_conversation = conversation_lib.conv_templates[model_args.version]
+    else:
+        conversation_lib.default_conversation = conversation_lib.conv_templates["vicuna_v1"]
+    if tokenizer is None:
+        import transformers
+        tokenizer = transformers.AutoTokenizer.from_pretrained(model_args.model_name_or_path, cache_dir=training_args.cache_dir,
+                                                                model_max_length=training_args.model_max_length, padding_side="right", use_fast=False)
+    data_args.image_processor = ClipImageProcessor(size=cfg.geometry["vision"]["image"])
+    data_args.is_multimodal = True
+    data_args.mm_use_im_start_end = model_args.mm_use_im_start_end
+    module = make_supervised_data_module(tokenizer=tokenizer, data_args=data_args)
+    trainer = LLaVATrainer(model=model, tokenizer=tokenizer, args=training_args, **module)
+    state = trainer.train()
+    if rank == 0 and training_args.output_dir:
+        os.makedirs(training_args.output_dir, exist_ok=True)
+        model.save_pretrained(training_args.output_dir)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return state
+
+
+if __name__ == "__main__":
+    train()

@@ -117,3 +117,65 @@ def test_grad_accumulation_and_optimizer_step(golden_dir):
     eng.optimizer_step(lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
     l1 = float(eng.forward(g["input_ids"], g["attention_mask"], g["labels"], images))
     assert l1 < l0
+
+
+def test_reference_api_surface_and_trainer(golden_dir, tmp_path):
+    """llava.model / llava.train entry points: model(**batch).loss.backward() reaches the engine; a 2-step trainer run on a
+    tiny LLaVA-JSON dataset (synthetic images, character tokenizer) works end to end."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import json as _json
+    from types import SimpleNamespace
+    from PIL import Image
+    from radvlm_amd.llava import conversation as conv_lib
+    from radvlm_amd.llava.mm_utils import ClipImageProcessor
+    from radvlm_amd.llava.model import LlavaConfig, LlavaLlamaForCausalLM
+    from radvlm_amd.llava.train.llava_trainer import LLaVATrainer
+    from radvlm_amd.llava.train.train import DataArguments, TrainingArguments, make_supervised_data_module
+    g, meta, images = _golden(golden_dir, "toy_e2e")
+    model = LlavaLlamaForCausalLM(LlavaConfig(geometry=GEOMETRIES["toy"]), device="cuda:0", init="portable")
+    out = model(input_ids=torch.from_numpy(g["input_ids"]), attention_mask=torch.from_numpy(g["attention_mask"]),
+                labels=torch.from_numpy(g["labels"]), images=images, image_sizes=None, modalities=["image"] * 3, output_logits=True)
+    assert abs(float(out.loss) - float(g["loss"])) < 5e-3 and tuple(out.logits.shape) == g["logits"].shape
+    out.loss.backward()
+    want = meta["grad_norms"]["lm_head.weight"]
+    assert abs(float(model.engine.G("lm_head.weight").float().norm()) - want) < 5e-2 * want
+    feats = model.get_vision_tower()(torch.stack(images))
+    assert float((feats.float().cpu() - torch.from_numpy(g["tower_features"])).abs().max()) < 3e-2 * float(np.abs(g["tower_features"]).max())
+    sd = model.state_dict()
+    assert "model.layers.1.mlp.down_proj.weight" in sd and "model.mm_projector.2.bias" in sd
+
+    class Ids:
+        def __init__(self, ids):
+            self.input_ids = ids
+
+    class Tok:
+        bos_token_id, pad_token_id, model_max_length, legacy, padding_side = 1, 0, 256, True, "right"
+
+        def __call__(self, s, **kw):
+            ids = [1]
+            for k, piece in enumerate(s.split("</s>")):
+                if k:
+                    ids.append(2)
+                ids.extend(3 + (ord(c) % 900) for c in piece)
+            return Ids(ids)
+
+    rng = np.random.default_rng(0)
+    recs = []
+    for i in range(6):
+        Image.fromarray(rng.integers(0, 255, (70, 90, 3), dtype=np.uint8)).save(tmp_path / f"im{i}.png")
+        recs.append({"id": f"s{i}", "image": f"im{i}.png", "conversations": [{"from": "human", "value": "<image>\nWhat is it?"},
+                                                                            {"from": "gpt", "value": f"Finding number {i}."}]})
+    recs.append({"id": "t", "conversations": [{"from": "human", "value": "Hello there"}, {"from": "gpt", "value": "General reply."}]})
+    (tmp_path / "d.json").write_text(_json.dumps(recs))
+    conv_lib.default_conversation = conv_lib.conv_templates["v1"]
+    da = DataArguments(data_path=str(tmp_path / "d.json"), image_folder=str(tmp_path), image_aspect_ratio="pad", is_multimodal=True)
+    da.image_processor = ClipImageProcessor(56)
+    da.mm_use_im_start_end = False
+    tok = Tok()
+    module = make_supervised_data_module(tokenizer=tok, data_args=da)
+    assert module["train_dataset"].modality_lengths[-1] < 0
+    args = TrainingArguments(per_device_train_batch_size=2, gradient_accumulation_steps=2, max_steps=3, learning_rate=1e-3,
+                             group_by_modality_length=True, warmup_ratio=0.0)
+    state = LLaVATrainer(model=model, tokenizer=tok, args=args, **module).train()
+    assert state["global_step"] == 3 and all(np.isfinite(r["loss"]) for r in state["log_history"])

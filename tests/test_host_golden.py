@@ -1,0 +1,217 @@
+"""CPU tests of the host-side rows against golden vectors produced by the
+reference's own functions (tests/golden/make_golden_host.py, make_golden.py)."""
+import copy
+import json
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from radvlm_amd import splice as SP
+from radvlm_amd.llava import conversation as conv_lib
+from radvlm_amd.llava import mm_utils as MU
+from radvlm_amd.llava.train import llava_trainer as LT
+from radvlm_amd.llava.train import train as TR
+
+
+@pytest.fixture(scope="module")
+def H(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "host_golden.json")))
+
+
+class Ids:
+    def __init__(self, ids):
+        self.input_ids = ids
+
+
+class CharTok:
+    bos_token_id = 1
+    pad_token_id = 0
+    model_max_length = 512
+    legacy = True
+    padding_side = "right"
+
+    def __call__(self, s, **kw):
+        ids = [1]
+        for k, piece in enumerate(s.split("</s>")):
+            if k:
+                ids.append(2)
+            ids.extend(ord(c) for c in piece)
+        return Ids(ids)
+
+
+def img(seed, w, h):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 255, size=(h // 8 + 2, w // 8 + 2, 3), dtype=np.uint8)
+    return Image.fromarray(base).resize((w, h), Image.BICUBIC)
+
+
+def test_samplers(H):
+    for c in H["samplers"]:
+        L, ML, bs, ws = c["lengths"], c["modality_lengths"], c["batch_size"], c["world_size"]
+        for fn, ln in (("get_length_grouped_indices", L), ("get_length_grouped_indices_auto_single", L),
+                       ("get_variable_length_grouped_indices", L), ("get_modality_length_grouped_indices", ML),
+                       ("get_modality_length_grouped_indices_auto", ML)):
+            g = torch.Generator().manual_seed(c["seed"])
+            torch.manual_seed(1000 + c["seed"])  # inner permutations of the modality variants use the global generator
+            got = [int(i) for i in getattr(LT, fn)(ln, bs, ws, generator=g)]
+            assert got == c[fn], fn
+        srt = sorted(range(c["n"]), key=lambda i: L[i], reverse=True)[: (c["n"] // ws) * ws]
+        assert LT.split_to_even_chunks(srt, L, ws) == c["split_to_even_chunks"]
+    # sampler object + rank sharding: disjoint, equal-sized shards
+    c = H["samplers"][0]
+    s = LT.LengthGroupedSampler(c["batch_size"], c["world_size"], lengths=c["modality_lengths"], group_by_modality=True,
+                                generator=torch.Generator().manual_seed(c["seed"]))
+    torch.manual_seed(1000 + c["seed"])
+    order = list(iter(s))
+    assert order == c["get_modality_length_grouped_indices"]
+    shards = [LT.shard_for_rank(order, c["batch_size"], 2, r) for r in range(2)]
+    assert len(shards[0]) == len(shards[1]) and not set(shards[0]) & set(shards[1])
+
+
+def test_collator(H):
+    c = H["collator"]
+    tok = CharTok()
+    tok.model_max_length = 12
+    inst = [dict(input_ids=torch.tensor([1, 5, -200, 7, 8]), labels=torch.tensor([-100, -100, -100, 7, 8]),
+                 image=[(torch.zeros(3, 4, 4), (640, 480), "image")]),
+            dict(input_ids=torch.arange(1, 20), labels=torch.arange(1, 20), image=[(torch.zeros(1, 3, 4, 4), (4, 4), "text")]),
+            dict(input_ids=torch.tensor([1, 9]), labels=torch.tensor([-100, 9]),
+                 image=[(torch.zeros(5, 3, 4, 4), (1000, 700), "image"), (torch.zeros(3, 4, 4), (10, 10), "image")])]
+    b = TR.DataCollatorForSupervisedDataset(tokenizer=tok)(inst)
+    assert b["input_ids"].tolist() == c["input_ids"] and b["labels"].tolist() == c["labels"]
+    assert b["attention_mask"].tolist() == c["attention_mask"]
+    assert [list(s) for s in b["image_sizes"]] == c["image_sizes"] and b["modalities"] == c["modalities"]
+    assert [list(i.shape) for i in b["images"]] == c["image_shapes"]
+
+
+def test_preprocessors(H):
+    p = H["preprocess"]
+    da = SimpleNamespace(is_multimodal=True, mm_use_im_start_end=False)
+    pm = TR.preprocess_multimodal(copy.deepcopy(p["conversations"]), da)
+    assert pm == p["multimodal"]
+    tok = CharTok()
+    tok.model_max_length = 2048
+    conv_lib.default_conversation = conv_lib.conv_templates["v1"]
+    try:
+        for conv, want in zip(copy.deepcopy(pm), p["v1"]):
+            d = TR.preprocess_v1([conv], tok, has_image=True)
+            assert d["input_ids"][0].tolist() == want["input_ids"]
+            assert d["labels"][0].tolist() == want["labels"]
+            assert any(l != -100 for l in want["labels"])  # the golden case exercises real answer spans
+        conv_lib.default_conversation = conv_lib.conv_templates["plain"]
+        d = TR.preprocess_plain([copy.deepcopy(pm[1])], tok)
+        assert d["input_ids"][0].tolist() == p["plain"]["input_ids"] and d["labels"][0].tolist() == p["plain"]["labels"]
+    finally:
+        conv_lib.default_conversation = conv_lib.conv_templates["v1"]
+
+
+def test_llava_json_cells(H):
+    from radvlm_amd.data import create_json_cell_llava, generate_llava_dataset_from_instruction_dataset
+    j = H["json_cells"]
+    ds = SimpleNamespace(pathologies=["Edema", "Effusion"])
+    for i, (s, want) in enumerate(zip(j["samples"], j["cells"])):
+        assert create_json_cell_llava(s, "pre", 10 + i, ds if i == 1 else None) == want
+    cells = generate_llava_dataset_from_instruction_dataset([dict(dataset=j["samples"], id_prefix="x", num_samples=2),
+                                                             dict(dataset=j["samples"], id_prefix="y")])
+    assert len(cells) == 5 and [c["id"] for c in cells] == ["x_0", "x_1", "y_2", "y_3", "y_4"]
+    assert all(c["conversations"][0]["value"].startswith("<image>\n") for c in cells)
+
+
+def test_image_geometry(H, golden_dir):
+    A = np.load(os.path.join(golden_dir, "host_images.npz"))
+    for k, g in enumerate(H["image_geometry"]):
+        im = img(k, *g["size"])
+        rp = MU.resize_and_pad_image(im, tuple(g["target"]))
+        assert int(np.asarray(rp, dtype=np.int64).sum()) == g["resize_pad_sum"]
+        assert np.array_equal(np.asarray(rp)[::8, ::8], A[f"resize_pad{k}"])
+        patches = MU.divide_to_patches(rp, 336)
+        assert len(patches) == g["n_patches"] and np.array_equal(np.asarray(patches[-1])[::8, ::8], A[f"patch_last{k}"])
+        sq = MU.expand2square(im, (122, 116, 104))
+        assert list(sq.size) == g["square_size"] and int(np.asarray(sq, dtype=np.int64).sum()) == g["square_sum"]
+    # CLIP preprocessing + anyres tiling: this build's processor vs HF CLIPImageProcessor driven by the reference code
+    proc = MU.ClipImageProcessor(336)
+    pin = [[336, 672], [672, 336], [672, 672], [1008, 336], [336, 1008]]
+    t = MU.process_anyres_image(img(0, 500, 400), proc, pin)
+    assert list(t.shape) == H["anyres0_shape"]
+    assert np.abs(t.numpy()[:, :, ::16, ::16] - A["anyres0"]).max() < 2e-2   # 8-bit resampling rounding differences only
+    assert np.abs(t.numpy().reshape(t.shape[0], -1).mean(1) - A["anyres0_mean"]).max() < 1e-3
+    one = proc.preprocess(img(1, 300, 900))["pixel_values"][0]
+    assert np.abs(one.numpy()[:, ::8, ::8] - A["clip_pre1"]).max() < 2e-2
+    cfg = SimpleNamespace(image_aspect_ratio="pad", image_grid_pinpoints=pin)
+    out = MU.process_images([img(2, 200, 100), img(3, 100, 100)], proc, cfg)
+    assert tuple(out.shape) == (2, 3, 336, 336)
+
+
+def test_splice_plan_against_reference(golden_dir):
+    """Index plan == the reference's spliced labels / mask for flat and for anyres + spatial_unpad."""
+    for name in ("toy_e2e", "toy_anyres_e2e"):
+        g = np.load(os.path.join(golden_dir, name + ".npz"))
+        meta = json.load(open(os.path.join(golden_dir, name + "_gradnorms.json")))
+        n = len([k for k in g.files if k.startswith("image") and k[5:].isdigit()])
+        rows, r0 = [], 0
+        for i in range(n):
+            im = g[f"image{i}"]
+            t = 1 if im.ndim == 3 else im.shape[0]
+            rows.append(SP.merged_feature_rows(r0, t, 4, meta["merge_type"], meta["aspect"], tuple(g["image_sizes"][i]),
+                                               meta["pinpoints"], 56))
+            r0 += t * 16
+        plan = SP.build_splice_plan(g["input_ids"], g["attention_mask"], g["labels"], rows, r0)
+        assert np.array_equal(plan["labels"], g["splice_labels"])
+        assert np.array_equal(plan["attention_mask"], g["splice_attention_mask"])
+        # every used projector row lands exactly once; CSR covers every text token
+        used = plan["feat_pos"][plan["feat_pos"] >= 0]
+        assert len(set(used.tolist())) == used.size
+        assert plan["tok_off"][-1] == int((plan["idx"] >= 0).sum())
+        emb = g["inputs_embeds"]
+        pad = ~g["splice_attention_mask"]
+        assert np.all(plan["idx"].reshape(pad.shape)[pad] == -1) and float(np.abs(emb[pad]).max()) == 0.0
+
+
+def test_splice_truncation_and_text_only():
+    ids = np.array([[5, -200, 6, 7], [8, 9, 0, 0]])
+    mask = np.array([[1, 1, 1, 1], [1, 1, 0, 0]], dtype=bool)
+    labels = np.array([[-100, -100, 6, 7], [-100, 9, -100, -100]])
+    rows = [np.arange(0, 4), np.arange(4, 8)]  # second sample is text-only: its (dummy) rows stay unused
+    plan = SP.build_splice_plan(ids, mask, labels, rows, 8, max_len=5)
+    assert plan["S"] == 5 and plan["lens"].tolist() == [5, 2]
+    assert plan["idx"].reshape(2, 5).tolist() == [[5, -2, -3, -4, -5], [8, 9, -1, -1, -1]]
+    assert plan["labels"].tolist() == [[-100, -100, -100, -100, -100], [-100, 9, -100, -100, -100]]
+    assert plan["feat_pos"].tolist() == [1, 2, 3, 4, -1, -1, -1, -1]
+    assert SP.shifted_labels(plan["labels"]).tolist() == [[-100] * 5, [9, -100, -100, -100, -100]]
+
+
+def test_optimizer_groups_and_schedule():
+    from radvlm_amd.config import GEOMETRIES
+    from radvlm_amd.params import FlatParams, lm_param_shapes
+    fp = FlatParams(lm_param_shapes(GEOMETRIES["toy"], True), "cpu")
+    eng = SimpleNamespace(lm=fp)
+    from radvlm_amd.engine import LlavaEngine
+    groups = LlavaEngine.param_groups(eng, lr=1e-3, weight_decay=0.1, mm_projector_lr=5e-4)
+    covered = np.zeros(fp.numel, dtype=bool)
+    for s, e, lr, wd in groups:
+        assert not covered[s:e].any()
+        covered[s:e] = True
+    for name in fp.names():
+        off, n = fp.offsets[name]
+        (g,) = [g for g in groups if g[0] <= off and off + n <= g[1]]
+        is_norm_or_bias = ("norm" in name and name.endswith("weight")) or name.endswith("bias")
+        assert g[3] == (0.0 if is_norm_or_bias else 0.1), name          # llava_trainer.py:369-403: no decay on norms/biases
+        assert g[2] == (5e-4 if "mm_projector" in name else 1e-3), name  # separate projector LR
+    assert LT.cosine_lr(0, 100, 1.0, 10) == 0.0 and LT.cosine_lr(10, 100, 1.0, 10) == 1.0
+    assert abs(LT.cosine_lr(55, 100, 1.0, 10) - 0.5) < 1e-9 and LT.cosine_lr(100, 100, 1.0, 10) < 1e-9
+
+
+def test_arg_parsing_and_tunable_parts():
+    m, d, t = TR.parse_args_into_dataclasses(["--model_name_or_path", "lmsys/vicuna-7b-v1.5", "--version", "v1", "--bf16", "True",
+                                              "--mm_projector_type", "mlp2x_gelu", "--mm_vision_select_layer", "-2",
+                                              "--per_device_train_batch_size", "4", "--deepspeed", "zero3.json",
+                                              "--image_aspect_ratio", "pad", "--learning_rate", "2e-5", "--group_by_modality_length", "True"])
+    assert m.version == "v1" and m.mm_vision_select_layer == -2 and d.image_aspect_ratio == "pad"
+    assert t.per_device_train_batch_size == 4 and t.deepspeed == "zero3.json" and t.group_by_modality_length is True
+    assert TR.tunable_parts(m) == {"mm_mlp_adapter", "mm_language_model"}
+    m.mm_tunable_parts = "mm_vision_tower,mm_mlp_adapter,mm_language_model"
+    assert "mm_vision_tower" in TR.tunable_parts(m)
