@@ -34,6 +34,8 @@ const char* rv_version(void);
 int rv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
                     const void* residual, int64_t ldr, int M, int N, int K, int act, int out_f32, int res_f32,
                     const void* zeros16, void* stream);
+/* Tuning hook: 0 = automatic tile selection (default), 1 = 128x128 tile kernel, 2 = 256x256 tile kernel. */
+int rv_gemm_select_kernel(int which);
 
 /* Batched strided transpose of bf16 matrices: out[bz][c][r] = in[bz][r][c], r < R, c < C; columns r in [R, R_pad)
  * of every output row are written as zero.  bz = b0 * nb1 + b1; offsets in elements.

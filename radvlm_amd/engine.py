@@ -69,6 +69,10 @@ class LlavaEngine:
         self.sync = FlatGradSync(self.grads, process_group) if self.world > 1 else None
         self.ctx = None
         self.grad_accum_started = False
+        # wgrad GEMMs run on a side stream so that their tail waves overlap the dgrad GEMMs' (and vice versa):
+        # 256x256 tiles quantise to whole rounds of 256 CUs, and the two GEMMs of a linear's backward are independent.
+        self.overlap_wgrad = False  # measured slower on MI355X (1052 vs 1029 ms/step): concurrent 1-block/CU GEMMs thrash L2
+        self._side = torch.cuda.Stream(device=self.device)
 
     # ------------------------------------------------------------------ weights
     def W(self, name):
@@ -261,7 +265,15 @@ class LlavaEngine:
         dyT = ops.transpose(dy, r_pad=mp)
         xT = ops.transpose(x, r_pad=mp)
         acc = self.grad_accum_started
-        ops.gemm_nt(dyT, xT, out=gw, residual=gw if acc else None)
+        if self.overlap_wgrad:
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                ops.gemm_nt(dyT, xT, out=gw, residual=gw if acc else None)
+            dyT.record_stream(self._side)
+            xT.record_stream(self._side)
+        else:
+            ops.gemm_nt(dyT, xT, out=gw, residual=gw if acc else None)
         if need_dx:
             N = dy.shape[1]
             return ops.gemm_nt(dy, wT[:, :N], out=dx_out)
@@ -338,6 +350,8 @@ class LlavaEngine:
                                  torch.from_numpy(plan["tok_ids"]).to(dev), ge)
         last = "model.image_newline" if self.with_newline else "model.mm_projector.2.bias"
         self._bucket_done("model.embed_tokens.weight", last)
+        if self.overlap_wgrad:
+            torch.cuda.current_stream().wait_stream(self._side)
         self.ctx = None
         self.grad_accum_started = True
 
@@ -346,6 +360,8 @@ class LlavaEngine:
         """Gradients of tensors first..last are final: start their all-reduce on the comm stream (RCCL), in place."""
         if self.sync is None or not self.sync_this_backward:
             return
+        if self.overlap_wgrad:
+            torch.cuda.current_stream().wait_stream(self._side)  # this bucket's wgrads ran on the side stream
         s, e = self.lm.span(first, last)
         self.sync.bucket_done(s, e)
 
