@@ -34,6 +34,15 @@ const char* rv_version(void);
 int rv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
                     const void* residual, int64_t ldr, int M, int N, int K, int act, int out_f32, int res_f32,
                     const void* zeros16, void* stream);
+/* General form: op(A)[M,K] * op(B)[N,K]^T with either operand stored contraction-major instead:
+ *   trans_a != 0: A is stored [K, M] (row stride lda);  trans_b != 0: B is stored [K, N] (row stride ldb).
+ * Lets the autograd GEMMs read their operands in place (hardware-transposed LDS reads, ds_read_b64_tr_b16):
+ *   dgrad dX[M,Kin] = dY[M,Nout] * W[Nout,Kin]        -> trans_b (W is [contraction, Kin]);
+ *   wgrad dW[Nout,Kin] = dY[M,Nout]^T * X[M,Kin]      -> trans_a and trans_b (both are [contraction=tokens, features]).
+ * Feature dimensions of transposed operands must be multiples of 8. */
+int rv_gemm_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
+                 const void* residual, int64_t ldr, int M, int N, int K, int trans_a, int trans_b, int act, int out_f32,
+                 int res_f32, const void* zeros16, void* stream);
 /* Tuning hook: 0 = automatic tile selection (default), 1 = 128x128 tile kernel, 2 = 256x256 tile kernel. */
 int rv_gemm_select_kernel(int which);
 

@@ -153,36 +153,92 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams P) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// v2: 256x256x64 block tile, 8 waves (2 M x 4 N), 128x64 per wave, ~1 block/CU (128 KiB LDS, <=256 VGPR).
-// Each K-tile is staged as four 16-KiB half-tiles (A rows 0-127 / 128-255, B rows 0-127 / 128-255), ONE half-tile
-// per phase, into a 2-deep ring; a K-tile is computed in four phases of 16 MFMAs (one 64x32 quadrant each).
-//   ph1: stage A0(t+1) | read A(mh0), B(nh0) | MFMA (mh0,nh0)
-//   ph2: stage A1(t+1) | read B(nh1)         | MFMA (mh0,nh1)      -- barrier: all B reads of tile t retired
+// v2: 256x256x64 block tile, 8 waves (2 M x 4 N), 128x64 per wave, 1 block/CU (all 160 KiB of LDS, <=256 VGPR).
+// Each K-tile is staged as four 16-KiB half-tiles (A rows 0-127 / 128-255, B rows 0-127 / 128-255), ONE half-tile per
+// phase, into a 3-deep A ring + 2-deep B ring (10 slots); a K-tile is computed in four phases of 16 MFMAs (one 64x32
+// quadrant each):
+//   ph1: stage A0(t+2) | read A(mh0), B(nh0) | MFMA (mh0,nh0)
+//   ph2: stage A1(t+2) | read B(nh1)         | MFMA (mh0,nh1)      -- barrier: all B reads of tile t retired
 //   ph3: stage B0(t+2) | read A(mh1)         | MFMA (mh1,nh1)
-//   ph4: stage B1(t+2) |                     | MFMA (mh1,nh0)      -- vmcnt(4): tile t+1 landed, B(t+2) still in flight
-// Both B sub-tiles stay in registers, so the B half of a ring slot is free after ph2 and the A half after ph3;
-// LDS-DMA loads therefore stay in flight across both barriers (counted vmcnt, raw s_barrier; never vmcnt(0) in the loop).
+//   ph4: stage B1(t+2) |                     | MFMA (mh1,nh0)      -- vmcnt(8): tile t+1 landed, ALL of tile t+2 in flight
+// Both B sub-tiles stay in registers, so the B slot of tile t is free after ph2 (reused by B(t+2) in ph3/ph4); the A slot
+// of tile t-1 is free after the end barrier (reused by A(t+2)).  Every load is issued >= one K-tile (~2k cycles) before
+// its first use, stays in flight across both barriers (counted vmcnt + raw s_barrier, never vmcnt(0) in the loop).
 constexpr int BM2 = 256, BN2 = 256;
 constexpr int HALF_BYTES = 128 * BK * 2;      // 16 KiB
-constexpr int KT_BYTES2 = 4 * HALF_BYTES;     // 64 KiB per K-tile: A0 A1 B0 B1
+constexpr int LDS_BYTES2 = 10 * HALF_BYTES;   // A ring: 3 tiles x 2 halves, B ring: 2 tiles x 2 halves
+constexpr int B_RING_OFF = 6 * HALF_BYTES;
 
-DEVINL void stage_half(const bf16* __restrict__ src, long ld, int row0, int nrows_total, int k0, int K, const bf16* zeros,
+// Normal operand (T = false): half-tile = [128 feature rows][64 contraction] (128-B rows), as in v1.
+// Transposed operand (T = true): the matrix is stored [contraction][features]; half-tile = [64 contraction rows]
+// [128 features] (256-B rows), read back with ds_read_b64_tr_b16 (hardware transpose: each 16-lane group gets a
+// 4 x 16 block column-major).  32-B granule g of row m is stored at granule g ^ f(m), f(m) = (m&3) | ((m>>3)&1)<<2,
+// which makes the 8 rows a 32-lane half touches land on 8 different granules (conflict-free).
+DEVINL int tswz(int m) { return ((m & 3) | (((m >> 3) & 1) << 2)) << 1; }
+
+template <bool T>
+DEVINL void stage_half(const bf16* __restrict__ src, long ld, int feat0, int nfeat, int k0, int K, const bf16* zeros,
                        char* lds, int wid, int lane) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int it = i * 8 + wid;           // wave-instruction index 0..15
         const int c = it * 64 + lane;         // 16-B chunk id 0..1023
-        const int r = c >> 3, p = c & 7;
-        const int lc = p ^ ((r >> 1) & 7);
-        const int gr = row0 + r, gk = k0 + lc * 8;
-        const bf16* g = (gr < nrows_total && gk < K) ? (src + (long)gr * ld + gk) : zeros;
+        const bf16* g;
+        if (!T) {
+            const int r = c >> 3, p = c & 7;
+            const int lc = p ^ ((r >> 1) & 7);
+            const int gr = feat0 + r, gk = k0 + lc * 8;
+            g = (gr < nfeat && gk < K) ? (src + (long)gr * ld + gk) : zeros;
+        } else {
+            const int r = c >> 4, p = c & 15;
+            const int lc = p ^ tswz(r);
+            const int gk = k0 + r, gf = feat0 + lc * 8;
+            g = (gk < K && gf < nfeat) ? (src + (long)gk * ld + gf) : zeros;
+        }
         glds16(g, lds + it * 1024);
     }
 }
 
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+// A fragment of 16 features (fbase .. fbase+15, fbase % 16 == 0) x 32 contraction (k-step kk).
+// Transposed operands are read with ds_read_b64_tr_b16 issued from inline asm: hipcc's waitcnt pass cannot see that
+// the builtin form does not alias the in-flight LDS-DMA stores and would drain vmcnt(0) before every read group
+// (measured: -25 % on the dgrad/wgrad forms).  The asm reads are retired by frag_wait4 (s_waitcnt lgkmcnt(0) that
+// names every destination, so no consumer is scheduled above it) -- guide section 5.7 form (ii).
+struct Frag { bf16x8 n; s16x4 t0, t1; };
+
+template <bool T>
+DEVINL void frag_issue(Frag& f, const char* tile, int fbase, int kk, int lane) {
+    if (!T) { f.n = read_frag(tile, fbase + (lane & 15), kk * 4 + (lane >> 4)); return; }
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int c16 = (fbase >> 3) + (p >> 1);
+    const int m0 = kk * 32 + 8 * g + q, m1 = m0 + 4;
+    const char* a0 = tile + m0 * 256 + ((c16 ^ tswz(m0)) << 4) + ((p & 1) << 3);
+    const char* a1 = tile + m1 * 256 + ((c16 ^ tswz(m1)) << 4) + ((p & 1) << 3);
+    const unsigned o0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)a0;
+    const unsigned o1 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)a1;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.t0) : "v"(o0) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.t1) : "v"(o1) : "memory");
+}
+template <bool T>
+DEVINL void frag_wait4(Frag& a, Frag& b, Frag& c, Frag& d) {
+    if (!T) return;
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a.t0), "+v"(a.t1), "+v"(b.t0), "+v"(b.t1), "+v"(c.t0), "+v"(c.t1), "+v"(d.t0), "+v"(d.t1) :: "memory");
+}
+template <bool T>
+DEVINL bf16x8 frag_get(const Frag& f) {
+    if (!T) return f.n;
+    const s16x8 r = {f.t0[0], f.t0[1], f.t0[2], f.t0[3], f.t1[0], f.t1[1], f.t1[2], f.t1[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
 #define BAR_LGKM() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-__global__ __launch_bounds__(512, 1) void gemm_nt_kernel_256(GemmParams P) {
+template <bool TA, bool TB>
+__global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wid = wave_id(), lane = lane_id();
     const int wr = wid >> 2, wc = wid & 3;
@@ -205,30 +261,43 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_kernel_256(GemmParams P) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nt = (P.K + BK - 1) / BK;
-    auto stageA = [&](int t, int h) { stage_half(P.A, P.lda, m0 + h * 128, P.M, t * BK, P.K, P.zeros, smem + (t & 1) * KT_BYTES2 + h * HALF_BYTES, wid, lane); };
-    auto stageB = [&](int t, int h) { stage_half(P.B, P.ldb, n0 + h * 128, P.N, t * BK, P.K, P.zeros, smem + (t & 1) * KT_BYTES2 + (2 + h) * HALF_BYTES, wid, lane); };
+    auto stageA = [&](int t, int slot, int h) { stage_half<TA>(P.A, P.lda, m0 + h * 128, P.M, t * BK, P.K, P.zeros, smem + (slot * 2 + h) * HALF_BYTES, wid, lane); };
+    auto stageB = [&](int t, int h) { stage_half<TB>(P.B, P.ldb, n0 + h * 128, P.N, t * BK, P.K, P.zeros, smem + B_RING_OFF + ((t & 1) * 2 + h) * HALF_BYTES, wid, lane); };
 
-    // prologue: all of tile 0, and the B halves of tile 1
-    stageA(0, 0); stageA(0, 1); stageB(0, 0); stageB(0, 1);
-    if (nt > 1) { stageB(1, 0); stageB(1, 1); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    // prologue: tiles 0 and 1 (tile 1 stays in flight)
+    stageA(0, 0, 0); stageA(0, 0, 1); stageB(0, 0); stageB(0, 1);
+    if (nt > 1) { stageA(1, 1, 0); stageA(1, 1, 1); stageB(1, 0); stageB(1, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    const int arow = lane & 15, kq = lane >> 4;
+    int aslot = 0;          // A ring slot of tile t (t % 3)
     for (int t = 0; t < nt; ++t) {
-        const char* At = smem + (t & 1) * KT_BYTES2 + wr * HALF_BYTES;
-        const char* Bt = smem + (t & 1) * KT_BYTES2 + (2 + (wc >> 1)) * HALF_BYTES;
+        const char* At = smem + (aslot * 2 + wr) * HALF_BYTES;
+        const char* Bt = smem + B_RING_OFF + ((t & 1) * 2 + (wc >> 1)) * HALF_BYTES;
+        const int aslot2 = aslot == 0 ? 2 : aslot - 1;   // (t + 2) % 3: the slot tile t-1 just vacated
         const int brow0 = (wc & 1) * 64;
+        Frag fa[4][2], fb[2][2][2];
         bf16x8 a[4][2], b[2][2][2];
 
         // ---- phase 1
-        if (t + 1 < nt) stageA(t + 1, 0);
+        if (t + 2 < nt) stageA(t + 2, aslot2, 0);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[0][j][kk] = read_frag(Bt, brow0 + j * 16 + arow, kk * 4 + kq);
+            for (int j = 0; j < 2; ++j) frag_issue<TB>(fb[0][j][kk], Bt, brow0 + j * 16, kk, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i][kk] = read_frag(At, i * 16 + arow, kk * 4 + kq);
+            for (int i = 0; i < 4; ++i) frag_issue<TA>(fa[i][kk], At, i * 16, kk, lane);
+        }
+        frag_wait4<TB>(fb[0][0][0], fb[0][1][0], fb[0][0][1], fb[0][1][1]);
+        frag_wait4<TA>(fa[0][0], fa[1][0], fa[2][0], fa[3][0]);
+        frag_wait4<TA>(fa[0][1], fa[1][1], fa[2][1], fa[3][1]);
+        if (TA || TB) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[0][j][kk] = frag_get<TB>(fb[0][j][kk]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i][kk] = frag_get<TA>(fa[i][kk]);
         }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -240,12 +309,18 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_kernel_256(GemmParams P) {
         __builtin_amdgcn_s_setprio(0);
 
         // ---- phase 2
-        if (t + 1 < nt) stageA(t + 1, 1);
+        if (t + 2 < nt) stageA(t + 2, aslot2, 1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[1][j][kk] = read_frag(Bt, brow0 + 32 + j * 16 + arow, kk * 4 + kq);
-        BAR_LGKM();   // every wave's B reads of tile t are complete -> the B halves of this slot may be restaged
+            for (int j = 0; j < 2; ++j) frag_issue<TB>(fb[1][j][kk], Bt, brow0 + 32 + j * 16, kk, lane);
+        BAR_LGKM();   // every wave's B reads of tile t are complete -> the B slot of tile t may be restaged
+        frag_wait4<TB>(fb[1][0][0], fb[1][1][0], fb[1][0][1], fb[1][1][1]);
+        if (TB) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[1][j][kk] = frag_get<TB>(fb[1][j][kk]);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -260,7 +335,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_kernel_256(GemmParams P) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i][kk] = read_frag(At, 64 + i * 16 + arow, kk * 4 + kq);
+            for (int i = 0; i < 4; ++i) frag_issue<TA>(fa[i][kk], At, 64 + i * 16, kk, lane);
+        frag_wait4<TA>(fa[0][0], fa[1][0], fa[2][0], fa[3][0]);
+        frag_wait4<TA>(fa[0][1], fa[1][1], fa[2][1], fa[3][1]);
+        if (TA) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i][kk] = frag_get<TA>(fa[i][kk]);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -280,9 +362,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_kernel_256(GemmParams P) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[4 + i][j] = mfma16(b[0][j][kk], a[i][kk], acc[4 + i][j]);
         __builtin_amdgcn_s_setprio(0);
-        // tile t+1 (A issued in ph1/ph2 of this tile, B one tile earlier) must have landed; B(t+2) may stay in flight
-        if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // tile t+1 (issued during tile t-1) must have landed; the 8 loads of tile t+2 stay in flight
+        if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        aslot = aslot == 2 ? 0 : aslot + 1;
         BAR_LGKM();   // also: every wave's A reads of tile t are complete -> the A halves of this slot may be restaged
     }
 
@@ -335,11 +418,19 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_kernel_256(GemmParams P) {
 static int g_force_kernel = 0;  // 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel (RV_GEMM_KERNEL or rv_gemm_select_kernel)
 extern "C" int rv_gemm_select_kernel(int which) { g_force_kernel = which; return RV_OK; }
 
-extern "C" int rv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                               const void* bias, const void* residual, int64_t ldr, int M, int N, int K, int act,
-                               int out_f32, int res_f32, const void* zeros16, void* stream) {
+template <bool TA, bool TB>
+static void launch256(const GemmParams& P, hipStream_t st) {
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute((const void*)gemm_kernel_256<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2); set = true; }
+    hipLaunchKernelGGL((gemm_kernel_256<TA, TB>), dim3(P.tiles_m * P.tiles_n), dim3(512), LDS_BYTES2, st, P);
+}
+
+extern "C" int rv_gemm_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
+                            const void* residual, int64_t ldr, int M, int N, int K, int trans_a, int trans_b, int act,
+                            int out_f32, int res_f32, const void* zeros16, void* stream) {
     if (!A || !B || !C || !zeros16 || M <= 0 || N <= 0 || K <= 0) return RV_ERR_ARG;
-    if ((K & 7) || (lda & 7) || (ldb & 7)) return RV_ERR_ARG;
+    if ((lda & 7) || (ldb & 7)) return RV_ERR_ARG;
+    if ((!trans_a && (K & 7)) || (trans_a && (M & 7)) || (!trans_b && (K & 7)) || (trans_b && (N & 7))) return RV_ERR_ARG;
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)zeros16) & 15) return RV_ERR_ARG;
     GemmParams P;
     P.A = (const bf16*)A; P.B = (const bf16*)B; P.C = C; P.bias = (const bf16*)bias; P.R = residual;
@@ -349,20 +440,28 @@ extern "C" int rv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel_256, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KT_BYTES2);
         const char* e = getenv("RV_GEMM_KERNEL");
         if (e) g_force_kernel = atoi(e);
         attr_set = true;
     }
     const long tiles256 = (long)((M + BM2 - 1) / BM2) * ((N + BN2 - 1) / BN2);
     const int force = g_force_kernel;
-    const bool use256 = force ? (force == 2) : (tiles256 >= 200);  // enough 256^2 tiles to fill the 256 CUs
+    // the 128x128 kernel only exists for the NT form; transposed operands always take the 256x256 kernel
+    const bool use256 = (trans_a || trans_b) ? true : (force ? (force == 2) : (tiles256 >= 200));
+    hipStream_t st = (hipStream_t)stream;
     if (use256) {
         P.tiles_m = (M + BM2 - 1) / BM2; P.tiles_n = (N + BN2 - 1) / BN2;
-        hipLaunchKernelGGL(gemm_nt_kernel_256, dim3(P.tiles_m * P.tiles_n), dim3(512), 2 * KT_BYTES2, (hipStream_t)stream, P);
+        if (trans_a) { if (trans_b) launch256<true, true>(P, st); else launch256<true, false>(P, st); }
+        else { if (trans_b) launch256<false, true>(P, st); else launch256<false, false>(P, st); }
     } else {
         P.tiles_m = (M + BM - 1) / BM; P.tiles_n = (N + BN - 1) / BN;
-        hipLaunchKernelGGL(gemm_nt_kernel, dim3(P.tiles_m * P.tiles_n), dim3(256), NSTAGE * STAGE_BYTES, (hipStream_t)stream, P);
+        hipLaunchKernelGGL(gemm_nt_kernel, dim3(P.tiles_m * P.tiles_n), dim3(256), NSTAGE * STAGE_BYTES, st, P);
     }
     return rv_check_launch();
+}
+
+extern "C" int rv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                               const void* bias, const void* residual, int64_t ldr, int M, int N, int K, int act,
+                               int out_f32, int res_f32, const void* zeros16, void* stream) {
+    return rv_gemm_bf16(A, lda, B, ldb, C, ldc, bias, residual, ldr, M, N, K, 0, 0, act, out_f32, res_f32, zeros16, stream);
 }

@@ -55,8 +55,6 @@ class LlavaEngine:
         elif init == "fast":
             fast_random_init_(self.lm, self.l["d"], seed)
             fast_random_init_(self.vis, self.l["d"], seed + 1)
-        self._wT = {}
-        self._wT_valid = False
         self._patch_w = None
         self._rope = {}
         self.master = self.m = self.vv = None
@@ -69,10 +67,6 @@ class LlavaEngine:
         self.sync = FlatGradSync(self.grads, process_group) if self.world > 1 else None
         self.ctx = None
         self.grad_accum_started = False
-        # wgrad GEMMs run on a side stream so that their tail waves overlap the dgrad GEMMs' (and vice versa):
-        # 256x256 tiles quantise to whole rounds of 256 CUs, and the two GEMMs of a linear's backward are independent.
-        self.overlap_wgrad = False  # measured slower on MI355X (1052 vs 1029 ms/step): concurrent 1-block/CU GEMMs thrash L2
-        self._side = torch.cuda.Stream(device=self.device)
 
     # ------------------------------------------------------------------ weights
     def W(self, name):
@@ -96,26 +90,7 @@ class LlavaEngine:
 
     def weights_changed(self):
         """Call after any in-place edit of the flat parameters (load_state_dict, optimizer step)."""
-        self._wT_valid = False
         self._patch_w = None
-
-    def _refresh_transposes(self):
-        """W^T copies for the dgrad GEMMs (the GEMM kernel wants both operands contraction-contiguous)."""
-        if self._wT_valid:
-            return
-        def T(key, w):
-            N, K = w.shape
-            buf = self._wT.get(key)
-            if buf is None:
-                buf = self._wT[key] = torch.empty(K, _ru(N, 8), dtype=BF16, device=self.device)
-            ops.transpose(w, r_pad=buf.shape[1], out=buf)
-        for i in range(self.l["layers"]):
-            lv = self._layer_views(i)
-            for k in ("qkv", "o", "gu", "down"):
-                T((i, k), lv[k])
-        T("lm_head", self.W("lm_head.weight"))
-        T("proj2", self.W("model.mm_projector.2.weight"))
-        self._wT_valid = True
 
     def rope_table(self, S):
         if S not in self._rope:
@@ -258,32 +233,19 @@ class LlavaEngine:
         return loss, loss_rows
 
     # ------------------------------------------------------------------ backward
-    def _linear_bwd(self, dy, x, wT, gw, need_dx=True, dx_out=None):
-        """dX = dY W (via W^T copy), dW = dY^T X (via transposed activations); writes dW into the flat grad view."""
-        M = dy.shape[0]
-        mp = _ru(M, 8)
-        dyT = ops.transpose(dy, r_pad=mp)
-        xT = ops.transpose(x, r_pad=mp)
+    def _linear_bwd(self, dy, x, w, gw, need_dx=True, dx_out=None):
+        """Backward of y = x W^T:  dW[N,K] = dY^T X  (both operands read contraction-major, in place) into the flat
+        grad view, and dX[M,K] = dY W (W read contraction-major) -- no transposed copies of weights or activations."""
         acc = self.grad_accum_started
-        if self.overlap_wgrad:
-            main = torch.cuda.current_stream()
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                ops.gemm_nt(dyT, xT, out=gw, residual=gw if acc else None)
-            dyT.record_stream(self._side)
-            xT.record_stream(self._side)
-        else:
-            ops.gemm_nt(dyT, xT, out=gw, residual=gw if acc else None)
+        ops.gemm(dy, x, ta=True, tb=True, out=gw, residual=gw if acc else None)
         if need_dx:
-            N = dy.shape[1]
-            return ops.gemm_nt(dy, wT[:, :N], out=dx_out)
+            return ops.gemm(dy, w, tb=True, out=dx_out)
         return None
 
     def backward(self):
         """Backward of the last forward(); gradients land in self.grads (bf16, flat)."""
         c = self.ctx
         assert c is not None, "forward() first"
-        self._refresh_transposes()
         l = self.l
         d, F, H, V, L = l["d"], l["ffn"], l["heads"], l["vocab"], l["layers"]
         hd = d // H
@@ -291,7 +253,7 @@ class LlavaEngine:
         acc = self.grad_accum_started
         cs = self.rope_table(S)
         # head
-        dhN = self._linear_bwd(c["dlogits"], c["hN"], self._wT["lm_head"], self.G("lm_head.weight"))
+        dhN = self._linear_bwd(c["dlogits"], c["hN"], self.W("lm_head.weight"), self.G("lm_head.weight"))
         dx, _ = ops.rmsnorm_bwd(dhN, c["x_last"], self.W("model.norm.weight"), c["rstdN"], dw=self.G("model.norm.weight"),
                                 dw_accumulate=acc)
         self._bucket_done("lm_head.weight", "lm_head.weight")
@@ -299,17 +261,17 @@ class LlavaEngine:
         for i in reversed(range(L)):
             a = c["layers"][i]
             lv, gv = self._layer_views(i), self._layer_views(i, self.grads)
-            dact = self._linear_bwd(dx, a["act"], self._wT[(i, "down")], gv["down"])
+            dact = self._linear_bwd(dx, a["act"], lv["down"], gv["down"])
             dgu = ops.swiglu_bwd(dact, a["gu"], F)
-            dh2 = self._linear_bwd(dgu, a["h2"], self._wT[(i, "gu")], gv["gu"])
+            dh2 = self._linear_bwd(dgu, a["h2"], lv["gu"], gv["gu"])
             ops.rmsnorm_bwd(dh2, a["x_mid"], lv["ln2"], a["rstd2"], dx=dx, dx_add=True, dw=gv["ln2"], dw_accumulate=acc)
-            dattn = self._linear_bwd(dx, a["attn"], self._wT[(i, "o")], gv["o"])
+            dattn = self._linear_bwd(dx, a["attn"], lv["o"], gv["o"])
             qkv = a["qkv"]
             dqkv = torch.empty_like(qkv)
             ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a["attn"], dattn, a["lse"], B, S, H, hd, s_pad, True,
                          lens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:])
             ops.rope_inplace(dqkv, cs, S, H, hd, 2, -1)
-            dh1 = self._linear_bwd(dqkv, a["h1"], self._wT[(i, "qkv")], gv["qkv"])
+            dh1 = self._linear_bwd(dqkv, a["h1"], lv["qkv"], gv["qkv"])
             ops.rmsnorm_bwd(dh1, a["x"], lv["ln1"], a["rstd1"], dx=dx, dx_add=True, dw=gv["ln1"], dw_accumulate=acc)
             c["layers"][i] = None  # free this layer's activations
             p = f"model.layers.{i}."
@@ -323,7 +285,7 @@ class LlavaEngine:
         dfeat = ops.gather_rows(fpos, d, dx)
         g = self.G
         ops.bias_grad(dfeat, out=g("model.mm_projector.2.bias"), accumulate=acc)
-        da1 = self._linear_bwd(dfeat, c["a1"], self._wT["proj2"], g("model.mm_projector.2.weight"))
+        da1 = self._linear_bwd(dfeat, c["a1"], self.W("model.mm_projector.2.weight"), g("model.mm_projector.2.weight"))
         dz1 = ops.gelu_bwd(da1, c["z1"])
         ops.bias_grad(dz1, out=g("model.mm_projector.0.bias"), accumulate=acc)
         self._linear_bwd(dz1, c["f0"], None, g("model.mm_projector.0.weight"), need_dx=False)
@@ -350,8 +312,6 @@ class LlavaEngine:
                                  torch.from_numpy(plan["tok_ids"]).to(dev), ge)
         last = "model.image_newline" if self.with_newline else "model.mm_projector.2.bias"
         self._bucket_done("model.embed_tokens.weight", last)
-        if self.overlap_wgrad:
-            torch.cuda.current_stream().wait_stream(self._side)
         self.ctx = None
         self.grad_accum_started = True
 
@@ -360,8 +320,6 @@ class LlavaEngine:
         """Gradients of tensors first..last are final: start their all-reduce on the comm stream (RCCL), in place."""
         if self.sync is None or not self.sync_this_backward:
             return
-        if self.overlap_wgrad:
-            torch.cuda.current_stream().wait_stream(self._side)  # this bucket's wgrads ran on the side stream
         s, e = self.lm.span(first, last)
         self.sync.bucket_done(s, e)
 

@@ -22,6 +22,8 @@ ACT_NONE, ACT_QUICK_GELU, ACT_GELU = 0, 1, 2
 _SIGS = {
     "rv_gemm_nt_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i32, _i32, _i32,
                         _i32, _i32, _i32, _c_void_p, _c_void_p],
+    "rv_gemm_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i32, _i32, _i32, _i32, _i32,
+                     _i32, _i32, _i32, _c_void_p, _c_void_p],
     "rv_transpose_bf16": [_c_void_p, _i64, _i64, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _c_void_p],
     "rv_rmsnorm_fwd": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _f32, _c_void_p],
     "rv_rmsnorm_bwd": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i32, _c_void_p, _i32, _i32, _i32, _c_void_p],

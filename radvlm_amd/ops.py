@@ -44,6 +44,27 @@ def gemm_nt(a, b, out=None, bias=None, residual=None, act=ACT_NONE, out_dtype=BF
     return out
 
 
+def gemm(a, b, ta=False, tb=False, out=None, bias=None, residual=None, act=ACT_NONE, out_dtype=BF16):
+    """out[M,N] = act(op(a) @ op(b)^T + bias) + residual with a stored [K,M] if ta else [M,K], b stored [K,N] if tb else [N,K]."""
+    _chk(a), _chk(b)
+    assert a.stride(1) == 1 and b.stride(1) == 1
+    (K, M) = a.shape if ta else a.shape[::-1]
+    (K2, N) = b.shape if tb else b.shape[::-1]
+    assert K == K2, (a.shape, b.shape, ta, tb)
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype in (BF16, torch.float32)
+    res_f32, ldr = 0, 0
+    if residual is not None:
+        assert residual.shape == (M, N) and residual.stride(1) == 1
+        res_f32, ldr = int(residual.dtype == torch.float32), residual.stride(0)
+    if bias is not None:
+        assert bias.numel() == N and bias.is_contiguous()
+    lib.call("rv_gemm_bf16", a, a.stride(0), b, b.stride(0), out, out.stride(0), bias, residual, ldr, M, N, K, int(ta), int(tb),
+             act, int(out.dtype == torch.float32), res_f32, lib.zeros16(a.device))
+    return out
+
+
 def transpose(x, r_pad=None, out=None):
     """x [R,C] (unit inner stride) -> [C, r_pad] with zero padding."""
     _chk(x)

@@ -275,3 +275,27 @@ def test_adamw_and_gradnorm(ops):
     assert relerr(gmaster, p) < 1e-5
     assert relerr(gm, m) < 1e-5 and relerr(gv, v) < 1e-4
     assert torch.equal(gp.cpu(), gmaster.cpu().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (200, 136, 104), (520, 264, 1000), (1024, 768, 2048)])
+@pytest.mark.parametrize("ta,tb", [(False, True), (True, True), (True, False), (False, False)])
+def test_gemm_transposed_operands(ops, M, N, K, ta, tb):
+    """rv_gemm_bf16 with contraction-major operands (hardware-transposed LDS reads) = the autograd dgrad / wgrad forms."""
+    a, b = rnd(33, (M, K)), rnd(34, (N, K))
+    ref = a.float() @ b.float().t()
+    ga = a.t().contiguous().cuda() if ta else a.cuda()
+    gb = b.t().contiguous().cuda() if tb else b.cuda()
+    out = ops.gemm(ga, gb, ta=ta, tb=tb, out_dtype=torch.float32)
+    assert relerr(out, ref) < 1e-5
+    res = rnd(35, (M, N)).cuda()
+    out2 = ops.gemm(ga, gb, ta=ta, tb=tb, residual=res)
+    assert relerr(out2, ref + res.float().cpu()) < TOL
+    # asymmetric integer data: exact result, catches any operand-layout permutation
+    ai = (torch.arange(M)[:, None] * 2 + torch.arange(K)[None, :] % 5 - 3).to(torch.bfloat16)
+    bi = (torch.arange(N)[:, None] % 7 - torch.arange(K)[None, :] % 3).to(torch.bfloat16)
+    gai = ai.t().contiguous().cuda() if ta else ai.cuda()
+    gbi = bi.t().contiguous().cuda() if tb else bi.cuda()
+    exact = ai.double() @ bi.double().t()
+    if float(exact.abs().max()) < 2 ** 24:
+        got = ops.gemm(gai, gbi, ta=ta, tb=tb, out_dtype=torch.float32)
+        assert torch.equal(got.cpu().double(), exact)
