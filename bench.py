@@ -46,7 +46,8 @@ def cpu_baseline(geo, seconds_budget=25.0):
     fwd+bwd and one ViT layer fwd at b=1 (S=704 / 577 tokens), scaled by layer counts, + lm_head/CE fwd+bwd."""
     from oracle import llava_oracle as O
     import torch.nn.functional as F
-    cores = os.cpu_count() or 1
+    # the GPU box grants this job a 16-core share of the host (more threads only oversubscribe: 256 threads ran 4x slower)
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     l, v = geo["lm"], geo["vision"]
     d, S = l["d"], 704
@@ -71,7 +72,7 @@ def cpu_baseline(geo, seconds_budget=25.0):
             fn()
         return (time.perf_counter() - t) / reps
 
-    t_dec = timeit(dec, 2)
+    t_dec = timeit(dec, 1)
     # ViT layer forward (frozen tower)
     dv, N = v["d"], (v["image"] // v["patch"]) ** 2 + 1
     vp = "model.vision_tower.vision_tower.vision_model."
@@ -79,7 +80,7 @@ def cpu_baseline(geo, seconds_budget=25.0):
     PV = {k: torch.randn(*shp, generator=g) * 0.02 for k, shp in O.param_shapes(geo1).items() if k.startswith(vp)}
     pix = torch.randn(1, 3, v["image"], v["image"], generator=g)
     with torch.no_grad():
-        t_vit = timeit(lambda: O.clip_vision_hidden(PV, geo1, pix, -2), 2)  # embeddings + 1 layer
+        t_vit = timeit(lambda: O.clip_vision_hidden(PV, geo1, pix, -2), 1)  # embeddings + 1 layer
     # head
     wh = (torch.randn(l["vocab"], d, generator=g) * 0.02).requires_grad_(True)
     hN = torch.randn(1, S, d, generator=g).requires_grad_(True)
