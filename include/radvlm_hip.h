@@ -60,8 +60,17 @@ int rv_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd, int rows,
  * (finish with rv_colsum_f32).  If dx_add != 0, dx += (residual-stream gradient accumulation). */
 int rv_rmsnorm_bwd(const void* dy, const void* x, const void* w, const float* rstd, void* dx, int dx_add,
                    float* dw_partial, int nblk, int rows, int d, void* stream);
-/* torch.nn.LayerNorm forward as used by CLIP (HF:modeling_clip.py:362-384, pre_layrnorm :744). */
-int rv_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int rows, int d, float eps, void* stream);
+/* torch.nn.LayerNorm as used by CLIP (HF:modeling_clip.py:362-384, pre_layrnorm :744).  stats (optional, fp32
+ * [rows,2] = mean, rstd) is saved for backward.  Backward: dx (+)= ..., partial[blk] = [sum dy*xhat (d) | sum dy (d)]
+ * (fp32 [nblk, 2d]; finish both halves with rv_colsum_f32) -- used when the vision tower is tunable
+ * (mm_tunable_parts contains mm_vision_tower, train/train.py:1658-1661). */
+int rv_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* stats, int rows, int d, float eps,
+                     void* stream);
+int rv_layernorm_bwd(const void* dy, const void* x, const void* w, const float* stats, void* dx, int dx_add,
+                     float* partial, int nblk, int rows, int d, void* stream);
+/* CLIP MLP activation x*sigmoid(1.702x) (HF:activations.py QuickGELUActivation) and its derivative. */
+int rv_quick_gelu_fwd(const void* x, void* y, int64_t n, void* stream);
+int rv_quick_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);
 
 /* out[c] (+)= sum_r in[r, c]  (fp32 partial rows -> bf16 vector). */
 int rv_colsum_f32(const float* in, int rows, int cols, void* out_bf16, int accumulate, void* stream);

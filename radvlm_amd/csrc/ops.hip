@@ -114,7 +114,7 @@ __global__ __launch_bounds__(TPB) void rmsnorm_bwd_kernel(const bf16* dy, const 
     }
 }
 
-__global__ __launch_bounds__(TPB) void layernorm_fwd_kernel(const bf16* x, const bf16* w, const bf16* b, bf16* y, int d, float eps) {
+__global__ __launch_bounds__(TPB) void layernorm_fwd_kernel(const bf16* x, const bf16* w, const bf16* b, bf16* y, float* stats, int d, float eps) {
     __shared__ float red[4];
     const long row = blockIdx.x;
     float xv[4][8];
@@ -139,6 +139,7 @@ __global__ __launch_bounds__(TPB) void layernorm_fwd_kernel(const bf16* x, const
         }
     }
     const float rstd = rsqrtf(block_sum<4>(v, red) / (float)d + eps);
+    if (stats && threadIdx.x == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int e = (p * TPB + threadIdx.x) * 8;
@@ -151,6 +152,91 @@ __global__ __launch_bounds__(TPB) void layernorm_fwd_kernel(const bf16* x, const
             st8(y + row * d + e, o);
         }
     }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * w;  partial[blk] = [sum dy*xhat (d) | sum dy (d)]
+__global__ __launch_bounds__(TPB) void layernorm_bwd_kernel(const bf16* dy, const bf16* x, const bf16* w, const float* stats,
+                                                            bf16* dx, int dx_add, float* partial, int rows, int d) {
+    __shared__ float red[4];
+    float dw[4][8], db[4][8], wv[4][8];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int e = (p * TPB + threadIdx.x) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { dw[p][i] = 0.f; db[p][i] = 0.f; }
+        if (e < d) ld8(w + e, wv[p]);
+    }
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float mean = stats[2 * row], rs = stats[2 * row + 1];
+        float xh[4][8], g[4][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int e = (p * TPB + threadIdx.x) * 8;
+            if (e < d) {
+                float xv[8], dv[8];
+                ld8(x + row * d + e, xv);
+                ld8(dy + row * d + e, dv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    xh[p][i] = (xv[i] - mean) * rs;
+                    g[p][i] = dv[i] * wv[p][i];
+                    s1 += g[p][i];
+                    s2 += g[p][i] * xh[p][i];
+                    dw[p][i] += dv[i] * xh[p][i];
+                    db[p][i] += dv[i];
+                }
+            }
+        }
+        s1 = block_sum<4>(s1, red) / (float)d;
+        s2 = block_sum<4>(s2, red) / (float)d;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int e = (p * TPB + threadIdx.x) * 8;
+            if (e < d) {
+                float o[8];
+                if (dx_add) ld8(dx + row * d + e, o);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float v = rs * (g[p][i] - s1 - xh[p][i] * s2);
+                    o[i] = dx_add ? o[i] + v : v;
+                }
+                st8(dx + row * d + e, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int e = (p * TPB + threadIdx.x) * 8;
+        if (e < d) {
+            float* o = partial + (long)blockIdx.x * 2 * d + e;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { o[i] = dw[p][i]; o[d + i] = db[p][i]; }
+        }
+    }
+}
+
+__global__ void quick_gelu_fwd_kernel(const bf16* x, bf16* y, long n8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    float v[8], o[8];
+    ld8(x + i * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = v[j] / (1.f + __expf(-1.702f * v[j]));
+    st8(y + i * 8, o);
+}
+__global__ void quick_gelu_bwd_kernel(const bf16* dy, const bf16* x, bf16* dx, long n8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    float v[8], g[8], o[8];
+    ld8(x + i * 8, v);
+    ld8(dy + i * 8, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float sg = 1.f / (1.f + __expf(-1.702f * v[j]));
+        o[j] = g[j] * sg * (1.f + 1.702f * v[j] * (1.f - sg));
+    }
+    st8(dx + i * 8, o);
 }
 
 // ------------------------------------------------------------------------------------------------ column sums
@@ -538,9 +624,26 @@ extern "C" int rv_rmsnorm_bwd(const void* dy, const void* x, const void* w, cons
                        (bf16*)dx, dx_add, dw_partial, rows, d);
     return rv_check_launch();
 }
-extern "C" int rv_layernorm_fwd(const void* x, const void* w, const void* b, void* y, int rows, int d, float eps, void* stream) {
+extern "C" int rv_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* stats, int rows, int d, float eps, void* stream) {
     if (!x || !w || !b || !y || rows <= 0 || (d & 7) || d > 8192) return RV_ERR_ARG;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(rows), dim3(TPB), 0, ST, (const bf16*)x, (const bf16*)w, (const bf16*)b, (bf16*)y, d, eps);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(rows), dim3(TPB), 0, ST, (const bf16*)x, (const bf16*)w, (const bf16*)b, (bf16*)y, stats, d, eps);
+    return rv_check_launch();
+}
+extern "C" int rv_layernorm_bwd(const void* dy, const void* x, const void* w, const float* stats, void* dx, int dx_add,
+                                float* partial, int nblk, int rows, int d, void* stream) {
+    if (!dy || !x || !w || !stats || !dx || !partial || nblk <= 0 || rows <= 0 || (d & 7) || d > 8192) return RV_ERR_ARG;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(TPB), 0, ST, (const bf16*)dy, (const bf16*)x, (const bf16*)w, stats,
+                       (bf16*)dx, dx_add, partial, rows, d);
+    return rv_check_launch();
+}
+extern "C" int rv_quick_gelu_fwd(const void* x, void* y, int64_t n, void* stream) {
+    if (!x || !y || n <= 0 || (n & 7)) return RV_ERR_ARG;
+    hipLaunchKernelGGL(quick_gelu_fwd_kernel, dim3(nblocks(n / 8, 256)), dim3(256), 0, ST, (const bf16*)x, (bf16*)y, (long)(n / 8));
+    return rv_check_launch();
+}
+extern "C" int rv_quick_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream) {
+    if (!dy || !x || !dx || n <= 0 || (n & 7)) return RV_ERR_ARG;
+    hipLaunchKernelGGL(quick_gelu_bwd_kernel, dim3(nblocks(n / 8, 256)), dim3(256), 0, ST, (const bf16*)dy, (const bf16*)x, (bf16*)dx, (long)(n / 8));
     return rv_check_launch();
 }
 extern "C" int rv_colsum_f32(const float* in, int rows, int cols, void* out, int accumulate, void* stream) {

@@ -32,7 +32,7 @@ def _ru(x, m):
 class LlavaEngine:
     def __init__(self, geo, device="cuda", merge_type="flat", image_aspect_ratio="square", image_grid_pinpoints=None,
                  max_len=None, init="portable", seed=0, rms_eps=1e-5, rope_theta=10000.0, process_group=None,
-                 bucket_layers=1):
+                 bucket_layers=1, train_vision_tower=False):
         self.geo = geo
         self.v, self.l = geo["vision"], geo["lm"]
         self.device = torch.device(device)
@@ -46,15 +46,27 @@ class LlavaEngine:
         self.side = self.v["image"] // self.v["patch"]
         self.P = self.side * self.side
         self.kp = _ru(3 * self.v["patch"] ** 2, 8)
-        self.lm = FlatParams(lm_param_shapes(geo, self.with_newline), self.device)
-        self.vis = FlatParams(vision_param_shapes(geo), self.device)
+        self.train_tower = train_vision_tower
+        if train_vision_tower:
+            # mm_tunable_parts contains mm_vision_tower (train/train.py:1658-1661): the tower joins the trainable flat
+            # buffer, in front (forward order), so its gradients are the last bucket of the backward pass
+            from collections import OrderedDict
+            shapes = OrderedDict(vision_param_shapes(geo))
+            shapes.update(lm_param_shapes(geo, self.with_newline))
+            self.lm = FlatParams(shapes, self.device)
+            self.vis = self.lm
+        else:
+            self.lm = FlatParams(lm_param_shapes(geo, self.with_newline), self.device)
+            self.vis = FlatParams(vision_param_shapes(geo), self.device)
         self.grads = self.lm.like(BF16)
         if init == "portable":
             portable_init_(self.lm, self.l["d"], seed)
-            portable_init_(self.vis, self.l["d"], seed)
+            if not train_vision_tower:
+                portable_init_(self.vis, self.l["d"], seed)
         elif init == "fast":
             fast_random_init_(self.lm, self.l["d"], seed)
-            fast_random_init_(self.vis, self.l["d"], seed + 1)
+            if not train_vision_tower:
+                fast_random_init_(self.vis, self.l["d"], seed + 1)
         self._patch_w = None
         self._rope = {}
         self.master = self.m = self.vv = None
@@ -105,8 +117,9 @@ class LlavaEngine:
             pw[:, :w.shape[1]] = w
             self._patch_w = pw
 
-    def vision_forward(self, pixels):
-        """pixels bf16 [n,3,H,W] -> hidden_states[-2] as rows [n*(P+1), dv] (clip_encoder.py:68-79, select_layer -2)."""
+    def vision_forward(self, pixels, save=None):
+        """pixels bf16 [n,3,H,W] -> hidden_states[-2] as rows [n*(P+1), dv] (clip_encoder.py:68-79, select_layer -2).
+        With `save` (tower tunable) the per-layer activations needed by vision_backward are kept."""
         v, f = self.v, self.vis
         self._vision_prepare()
         n = pixels.shape[0]
@@ -114,31 +127,104 @@ class LlavaEngine:
         hd = dv // H
         N = self.P + 1
         n_pad = _ru(N, 64)
+        keep = save is not None
         cols = ops.im2col_patches(pixels, v["patch"], self.kp)
         po = ops.gemm_nt(cols, self._patch_w)
-        x = ops.clip_embed(po, f.view(VP + "embeddings.class_embedding"), f.view(VP + "embeddings.position_embedding.weight"),
+        e = ops.clip_embed(po, f.view(VP + "embeddings.class_embedding"), f.view(VP + "embeddings.position_embedding.weight"),
                            n, self.P, dv)
-        x = ops.layernorm_fwd(x, f.view(VP + "pre_layrnorm.weight"), f.view(VP + "pre_layrnorm.bias"))
+        ln = lambda t, w, b: ops.layernorm_fwd(t, f.view(w), f.view(b), save_stats=keep)
+        r = ln(e, VP + "pre_layrnorm.weight", VP + "pre_layrnorm.bias")
+        x, st0 = r if keep else (r, None)
+        layers = []
         for i in range(v["layers"] - 1):  # hidden_states[-2] = input of the last layer
             p = VP + f"encoder.layers.{i}."
-            h = ops.layernorm_fwd(x, f.view(p + "layer_norm1.weight"), f.view(p + "layer_norm1.bias"))
+            r = ln(x, p + "layer_norm1.weight", p + "layer_norm1.bias")
+            h, st1 = r if keep else (r, None)
             wqkv = f.fused(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", 3 * dv, dv)
             bqkv = f.fused(p + "self_attn.q_proj.bias", p + "self_attn.v_proj.bias", 1, 3 * dv).view(-1)
             qkv = ops.gemm_nt(h, wqkv, bias=bqkv)
             vT = ops.transpose_heads(qkv[:, 2 * dv:], n, N, H, hd, n_pad)
-            a, _ = ops.attn_fwd(qkv[:, :dv], qkv[:, dv:2 * dv], vT, n, N, H, hd, n_pad, causal=False)
-            x = ops.gemm_nt(a, f.view(p + "self_attn.out_proj.weight"), bias=f.view(p + "self_attn.out_proj.bias"), residual=x)
-            h = ops.layernorm_fwd(x, f.view(p + "layer_norm2.weight"), f.view(p + "layer_norm2.bias"))
-            h = ops.gemm_nt(h, f.view(p + "mlp.fc1.weight"), bias=f.view(p + "mlp.fc1.bias"), act=ops.ACT_QUICK_GELU)
-            x = ops.gemm_nt(h, f.view(p + "mlp.fc2.weight"), bias=f.view(p + "mlp.fc2.bias"), residual=x)
+            a, lse = ops.attn_fwd(qkv[:, :dv], qkv[:, dv:2 * dv], vT, n, N, H, hd, n_pad, causal=False)
+            x1 = ops.gemm_nt(a, f.view(p + "self_attn.out_proj.weight"), bias=f.view(p + "self_attn.out_proj.bias"), residual=x)
+            r = ln(x1, p + "layer_norm2.weight", p + "layer_norm2.bias")
+            h2, st2 = r if keep else (r, None)
+            if keep:
+                z = ops.gemm_nt(h2, f.view(p + "mlp.fc1.weight"), bias=f.view(p + "mlp.fc1.bias"))
+                g = ops.quick_gelu_fwd(z)
+            else:
+                z = None
+                g = ops.gemm_nt(h2, f.view(p + "mlp.fc1.weight"), bias=f.view(p + "mlp.fc1.bias"), act=ops.ACT_QUICK_GELU)
+            x2 = ops.gemm_nt(g, f.view(p + "mlp.fc2.weight"), bias=f.view(p + "mlp.fc2.bias"), residual=x1)
+            if keep:
+                layers.append(dict(x=x, st1=st1, h=h, qkv=qkv, a=a, lse=lse, x1=x1, st2=st2, h2=h2, z=z, g=g))
+            x = x2
+        if keep:
+            save.update(v_cols=cols, v_e=e, v_st0=st0, v_layers=layers, v_n=n)
         return x
+
+    def vision_backward(self, dx, c):
+        """Backward of vision_forward: dx = d hidden_states[-2] [n*(P+1), dv]; parameter grads -> flat grad views."""
+        v, f, G = self.v, self.vis, self.G
+        n = c["v_n"]
+        dv, H = v["d"], v["heads"]
+        hd = dv // H
+        N = self.P + 1
+        n_pad = _ru(N, 64)
+        acc = self.grad_accum_started
+        W = lambda name: f.view(name)
+        for i in reversed(range(v["layers"] - 1)):
+            a = c["v_layers"][i]
+            p = VP + f"encoder.layers.{i}."
+            ops.bias_grad(dx, out=G(p + "mlp.fc2.bias"), accumulate=acc)
+            dg = self._linear_bwd(dx, a["g"], W(p + "mlp.fc2.weight"), G(p + "mlp.fc2.weight"))
+            dz = ops.quick_gelu_bwd(dg, a["z"])
+            ops.bias_grad(dz, out=G(p + "mlp.fc1.bias"), accumulate=acc)
+            dh2 = self._linear_bwd(dz, a["h2"], W(p + "mlp.fc1.weight"), G(p + "mlp.fc1.weight"))
+            ops.layernorm_bwd(dh2, a["x1"], W(p + "layer_norm2.weight"), a["st2"], G(p + "layer_norm2.weight"),
+                              G(p + "layer_norm2.bias"), dx=dx, dx_add=True, accumulate=acc)
+            ops.bias_grad(dx, out=G(p + "self_attn.out_proj.bias"), accumulate=acc)
+            da = self._linear_bwd(dx, a["a"], W(p + "self_attn.out_proj.weight"), G(p + "self_attn.out_proj.weight"))
+            qkv = a["qkv"]
+            dqkv = torch.empty_like(qkv)
+            ops.attn_bwd(qkv[:, :dv], qkv[:, dv:2 * dv], qkv[:, 2 * dv:], a["a"], da, a["lse"], n, N, H, hd, n_pad, False,
+                         dq=dqkv[:, :dv], dk=dqkv[:, dv:2 * dv], dv=dqkv[:, 2 * dv:])
+            gb = f.fused(p + "self_attn.q_proj.bias", p + "self_attn.v_proj.bias", 1, 3 * dv, self.grads).view(-1)
+            ops.bias_grad(dqkv, out=gb, accumulate=acc)
+            wqkv = f.fused(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", 3 * dv, dv)
+            gqkv = f.fused(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", 3 * dv, dv, self.grads)
+            dh = self._linear_bwd(dqkv, a["h"], wqkv, gqkv)
+            ops.layernorm_bwd(dh, a["x"], W(p + "layer_norm1.weight"), a["st1"], G(p + "layer_norm1.weight"),
+                              G(p + "layer_norm1.bias"), dx=dx, dx_add=True, accumulate=acc)
+            c["v_layers"][i] = None
+            self._bucket_done(p + "layer_norm1.weight", p + "mlp.fc2.bias")
+        de = ops.layernorm_bwd(dx, c["v_e"], W(VP + "pre_layrnorm.weight"), c["v_st0"], G(VP + "pre_layrnorm.weight"),
+                               G(VP + "pre_layrnorm.bias"), accumulate=acc)
+        # embeddings: position table = sum over images, class token = rows t = 0, patch conv = wgrad over im2col rows
+        de2 = de.view(n, N * dv)
+        ops.bias_grad(de2, out=G(VP + "embeddings.position_embedding.weight").view(-1), accumulate=acc)
+        ops.bias_grad(de2[:, :dv], out=G(VP + "embeddings.class_embedding"), accumulate=acc)
+        drop_cls = (torch.arange(n * self.P, device=self.device, dtype=torch.int32)
+                    + torch.arange(n, device=self.device, dtype=torch.int32).repeat_interleave(self.P) + 1)
+        dpo = ops.gather_rows(drop_cls, dv, de)
+        dwp = ops.gemm(dpo, c["v_cols"], ta=True, tb=True)
+        gp = G(VP + "embeddings.patch_embedding.weight").view(dv, -1)
+        k = gp.shape[1]
+        gp.add_(dwp[:, :k]) if acc else gp.copy_(dwp[:, :k])
+        # the last encoder layer and post_layernorm do not feed hidden_states[-2]: their gradients are zero
+        last = VP + f"encoder.layers.{v['layers'] - 1}."
+        s0, _ = self.lm.span(last + "layer_norm1.weight", last + "layer_norm1.weight")
+        _, e1 = self.lm.span(VP + "post_layernorm.bias", VP + "post_layernorm.bias")
+        if not acc:
+            self.grads[s0:e1].zero_()
+        self._bucket_done(VP + "embeddings.class_embedding", VP + "pre_layrnorm.bias")
+        self._bucket_done(last + "layer_norm1.weight", VP + "post_layernorm.bias")
 
     def encode_images(self, pixels, save=None):
         """encode_images (llava_arch.py:192-196): tower (patch features, CLS dropped) then mlp2x_gelu projector.
         Returns the feature table [n*P + 1, d]; its last row is reserved for image_newline."""
         n = pixels.shape[0]
         d = self.l["d"]
-        hid = self.vision_forward(pixels)
+        hid = self.vision_forward(pixels, save=save if (self.train_tower and save is not None) else None)
         drop_cls = (torch.arange(n * self.P, device=self.device, dtype=torch.int32)
                     + torch.arange(n, device=self.device, dtype=torch.int32).repeat_interleave(self.P) + 1)
         f0 = ops.gather_rows(drop_cls, self.v["d"], hid)
@@ -288,7 +374,8 @@ class LlavaEngine:
         da1 = self._linear_bwd(dfeat, c["a1"], self.W("model.mm_projector.2.weight"), g("model.mm_projector.2.weight"))
         dz1 = ops.gelu_bwd(da1, c["z1"])
         ops.bias_grad(dz1, out=g("model.mm_projector.0.bias"), accumulate=acc)
-        self._linear_bwd(dz1, c["f0"], None, g("model.mm_projector.0.weight"), need_dx=False)
+        df0 = self._linear_bwd(dz1, c["f0"], self.W("model.mm_projector.0.weight"), g("model.mm_projector.0.weight"),
+                               need_dx=self.train_tower)
         if self.with_newline:
             gn = g("model.image_newline").view(1, d)
             if not acc:
@@ -312,6 +399,13 @@ class LlavaEngine:
                                  torch.from_numpy(plan["tok_ids"]).to(dev), ge)
         last = "model.image_newline" if self.with_newline else "model.mm_projector.2.bias"
         self._bucket_done("model.embed_tokens.weight", last)
+        if self.train_tower:
+            n_img = c["v_n"]
+            N = self.P + 1
+            put = torch.full((n_img, N), -1, dtype=torch.int32, device=dev)
+            put[:, 1:] = torch.arange(n_img * self.P, device=dev, dtype=torch.int32).view(n_img, self.P)
+            dhid = ops.gather_rows(put.view(-1), self.v["d"], df0)   # CLS rows receive zero
+            self.vision_backward(dhid, c)
         self.ctx = None
         self.grad_accum_started = True
 
@@ -339,7 +433,7 @@ class LlavaEngine:
             self.m = self.lm.like(torch.float32)
             self.vv = self.lm.like(torch.float32)
 
-    def param_groups(self, lr, weight_decay=0.0, mm_projector_lr=None, no_decay_1d=True):
+    def param_groups(self, lr, weight_decay=0.0, mm_projector_lr=None, no_decay_1d=True, mm_vision_tower_lr=None):
         """Contiguous (start, end, lr, wd) slices following LLaVATrainer.create_optimizer (llava_trainer.py:369-418):
         no weight decay for norm weights and biases; optional separate LR for the projector."""
         groups = []
@@ -348,6 +442,8 @@ class LlavaEngine:
             shp = self.lm.shapes[name]
             nodecay = no_decay_1d and (len(shp) == 1 and ("norm" in name or name.endswith("bias")))
             glr = mm_projector_lr if (mm_projector_lr is not None and "mm_projector" in name) else lr
+            if mm_vision_tower_lr is not None and "vision_tower" in name:
+                glr = mm_vision_tower_lr
             gwd = 0.0 if nodecay else weight_decay
             if groups and groups[-1][2] == glr and groups[-1][3] == gwd and groups[-1][1] <= off:
                 groups[-1][1] = off + n  # merge (alignment gaps hold zeros and stay zero)
@@ -355,7 +451,8 @@ class LlavaEngine:
                 groups.append([off, off + n, glr, gwd])
         return [tuple(g) for g in groups]
 
-    def optimizer_step(self, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None, mm_projector_lr=None):
+    def optimizer_step(self, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None, mm_projector_lr=None,
+                       mm_vision_tower_lr=None):
         """AdamW over the flat buffers (fp32 master + moments), optional global-norm clipping without host sync."""
         self.init_optimizer()
         self.finish_grad_sync()
@@ -366,7 +463,7 @@ class LlavaEngine:
             nc = ops.grad_norm_clip_coef(self.grads, max_grad_norm)
             self.last_grad_norm = nc[0:1]
             coef = nc[1:2]
-        for s, e, glr, gwd in self.param_groups(lr, weight_decay, mm_projector_lr):
+        for s, e, glr, gwd in self.param_groups(lr, weight_decay, mm_projector_lr, mm_vision_tower_lr=mm_vision_tower_lr):
             ops.adamw(self.lm.flat[s:e], self.master[s:e], self.grads[s:e], self.m[s:e], self.vv[s:e], glr, betas[0], betas[1],
                       eps, gwd, self.opt_step, gscale=coef)
         self.weights_changed()
@@ -375,7 +472,7 @@ class LlavaEngine:
     # ------------------------------------------------------------------ state dict (reference names)
     def state_dict(self):
         out = {}
-        for fp in (self.lm, self.vis):
+        for fp in ((self.lm,) if self.vis is self.lm else (self.lm, self.vis)):
             for n in fp.names():
                 out[n] = fp.view(n)
         return out
@@ -383,7 +480,7 @@ class LlavaEngine:
     def load_state_dict(self, sd, strict=False):
         from .params import load_named
         m1, u1 = load_named(self.lm, sd)
-        m2, u2 = load_named(self.vis, {k: v for k, v in sd.items() if k in u1})
+        m2, u2 = ([], u1) if self.vis is self.lm else load_named(self.vis, {k: v for k, v in sd.items() if k in u1})
         self.weights_changed()
         if self.master is not None:
             self.master.copy_(ops.to_f32(self.lm.flat))

@@ -27,7 +27,10 @@ _SIGS = {
     "rv_transpose_bf16": [_c_void_p, _i64, _i64, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _c_void_p],
     "rv_rmsnorm_fwd": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _f32, _c_void_p],
     "rv_rmsnorm_bwd": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i32, _c_void_p, _i32, _i32, _i32, _c_void_p],
-    "rv_layernorm_fwd": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _f32, _c_void_p],
+    "rv_layernorm_fwd": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _f32, _c_void_p],
+    "rv_layernorm_bwd": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i32, _c_void_p, _i32, _i32, _i32, _c_void_p],
+    "rv_quick_gelu_fwd": [_c_void_p, _c_void_p, _i64, _c_void_p],
+    "rv_quick_gelu_bwd": [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p],
     "rv_colsum_f32": [_c_void_p, _i32, _i32, _c_void_p, _i32, _c_void_p],
     "rv_colsum_partial_bf16": [_c_void_p, _i64, _i32, _i32, _c_void_p, _i32, _c_void_p],
     "rv_rope_inplace": [_c_void_p, _i64, _c_void_p, _i32, _i32, _i32, _i32, _i32, _i32, _c_void_p],

@@ -19,7 +19,7 @@ class LlavaConfig:
     model_type = "llava_llama"
 
     def __init__(self, geometry=None, mm_patch_merge_type="flat", image_aspect_ratio="square", image_grid_pinpoints=None,
-                 tokenizer_model_max_length=None, rms_norm_eps=1e-5, rope_theta=10000.0, **kw):
+                 tokenizer_model_max_length=None, rms_norm_eps=1e-5, rope_theta=10000.0, unfreeze_mm_vision_tower=False, **kw):
         from ...config import GEOMETRIES
         self.geometry = geometry or GEOMETRIES["llava15_7b"]
         l, v = self.geometry["lm"], self.geometry["vision"]
@@ -38,6 +38,7 @@ class LlavaConfig:
         self.tokenizer_padding_side = "right"
         self.use_cache = False
         self.use_mm_proj = True
+        self.unfreeze_mm_vision_tower = unfreeze_mm_vision_tower
         for k, val in kw.items():
             setattr(self, k, val)
 
@@ -140,7 +141,8 @@ class LlavaLlamaForCausalLM:
         self.engine = LlavaEngine(config.geometry, device=device, merge_type=config.mm_patch_merge_type,
                                   image_aspect_ratio=config.image_aspect_ratio, image_grid_pinpoints=config.image_grid_pinpoints,
                                   max_len=config.tokenizer_model_max_length, init=init, seed=seed, rms_eps=config.rms_norm_eps,
-                                  rope_theta=config.rope_theta, process_group=process_group)
+                                  rope_theta=config.rope_theta, process_group=process_group,
+                                  train_vision_tower=getattr(config, "unfreeze_mm_vision_tower", False))
         self.model = LlavaLlamaModel(self.engine, config)
         self.training = True
         # a leaf that makes loss require grad so that `.backward()` reaches the engine

@@ -199,7 +199,8 @@ class LLaVATrainer:
             lr = cosine_lr(step, total, a.learning_rate, warm)
             eng.optimizer_step(lr=lr, weight_decay=a.weight_decay, betas=(getattr(a, "adam_beta1", 0.9), getattr(a, "adam_beta2", 0.999)),
                                eps=getattr(a, "adam_epsilon", 1e-8), max_grad_norm=getattr(a, "max_grad_norm", 1.0),
-                               mm_projector_lr=getattr(a, "mm_projector_lr", None))
+                               mm_projector_lr=getattr(a, "mm_projector_lr", None),
+                               mm_vision_tower_lr=getattr(a, "mm_vision_tower_lr", None))
             self.state["global_step"] = step
             if step % max(1, getattr(a, "logging_steps", 1)) == 0:
                 rec = {"step": step, "loss": float(sum(float(l) for l in losses) / len(losses)), "learning_rate": lr,

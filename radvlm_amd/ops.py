@@ -114,12 +114,48 @@ def rmsnorm_bwd(dy, x, w, rstd, dx=None, dx_add=False, dw=None, dw_accumulate=Fa
     return dx, dw
 
 
-def layernorm_fwd(x, w, b, eps=1e-5, y=None):
+def layernorm_fwd(x, w, b, eps=1e-5, y=None, save_stats=False):
     rows, d = x.shape
     assert x.is_contiguous()
     y = torch.empty_like(x) if y is None else y
-    lib.call("rv_layernorm_fwd", x, w, b, y, rows, d, eps)
+    stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device) if save_stats else None
+    lib.call("rv_layernorm_fwd", x, w, b, y, stats, rows, d, eps)
+    return (y, stats) if save_stats else y
+
+
+def layernorm_bwd(dy, x, w, stats, dw, db, dx=None, dx_add=False, accumulate=False):
+    """dx (+)= LN'(dy); dw/db (bf16 [d] views) (+)= parameter gradients."""
+    rows, d = x.shape
+    assert dy.is_contiguous() and x.is_contiguous()
+    nblk = min(rows, 512)
+    part = torch.empty(nblk, 2 * d, dtype=torch.float32, device=x.device)
+    if dx is None:
+        dx = torch.empty_like(x)
+        dx_add = False
+    lib.call("rv_layernorm_bwd", dy, x, w, stats, dx, int(dx_add), part, nblk, rows, d)
+    wb = torch.empty(2 * d, dtype=BF16, device=x.device)
+    lib.call("rv_colsum_f32", part, nblk, 2 * d, wb, 0)
+    if accumulate:
+        lib.call("rv_add_bf16", dw, wb[:d], dw, d)
+        lib.call("rv_add_bf16", db, wb[d:], db, d)
+    else:
+        dw.copy_(wb[:d])
+        db.copy_(wb[d:])
+    return dx
+
+
+def quick_gelu_fwd(x, y=None):
+    assert x.is_contiguous()
+    y = torch.empty_like(x) if y is None else y
+    lib.call("rv_quick_gelu_fwd", x, y, x.numel())
     return y
+
+
+def quick_gelu_bwd(dy, x, dx=None):
+    assert x.is_contiguous() and dy.is_contiguous()
+    dx = torch.empty_like(x) if dx is None else dx
+    lib.call("rv_quick_gelu_bwd", dy, x, dx, x.numel())
+    return dx
 
 
 def bias_grad(dy, out=None, accumulate=False):

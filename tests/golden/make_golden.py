@@ -105,9 +105,11 @@ def make_batch(geo, spec, seed_img=1, seed_ids=2, tiles=None):
 
 
 def run_e2e(mods, geo_name, spec, out_name, grads_full=(), merge_type="flat", aspect="square", pinpoints=None,
-            tiles=None, image_sizes=None):
+            tiles=None, image_sizes=None, unfreeze_tower=False):
     geo = GEOMETRIES[geo_name]
     model = build_reference_model(mods, geo, merge_type=merge_type, aspect=aspect, pinpoints=pinpoints)
+    if unfreeze_tower:  # mm_tunable_parts contains mm_vision_tower (train/train.py:1658-1661)
+        model.get_model().get_vision_tower().vision_tower.requires_grad_(True)
     ids, labels, mask, images, modalities = make_batch(geo, spec, tiles=tiles)
     imgs = [torch.from_numpy(x) for x in images]
     sizes = image_sizes or [[geo["vision"]["image"]] * 2 for _ in images]
@@ -273,7 +275,7 @@ def host_functions(mods):
 
 if __name__ == "__main__":
     mods = ref_shim.load_reference()
-    which = sys.argv[1:] or ["per_op", "host", "toy", "cfg1", "anyres"]
+    which = sys.argv[1:] or ["per_op", "host", "toy", "cfg1", "anyres", "tower"]
     if "per_op" in which:
         per_op(mods)
     if "host" in which:
@@ -293,5 +295,12 @@ if __name__ == "__main__":
         run_e2e(mods, "toy", [(14, 4, 6), (10, 2, 3)], "toy_anyres_e2e", merge_type="spatial_unpad", aspect="anyres",
                 pinpoints=pin, tiles=tiles, image_sizes=sizes,
                 grads_full=("model.image_newline", "model.mm_projector.2.weight"))
+    if "tower" in which:
+        vp = "model.vision_tower.vision_tower.vision_model."
+        run_e2e(mods, "toy", [(20, 5, 8), (12, 3, 4), (9, None, 2)], "toy_tower_e2e", unfreeze_tower=True,
+                grads_full=(vp + "embeddings.patch_embedding.weight", vp + "embeddings.position_embedding.weight",
+                            vp + "embeddings.class_embedding", vp + "encoder.layers.0.self_attn.q_proj.weight",
+                            vp + "encoder.layers.1.mlp.fc1.bias", vp + "encoder.layers.0.layer_norm1.weight",
+                            vp + "pre_layrnorm.bias", "model.mm_projector.0.weight"))
     if "cfg1" in which:
         run_e2e(mods, "config1", [(48, 35, 40)], "config1_e2e")

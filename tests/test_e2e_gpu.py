@@ -53,11 +53,15 @@ def _check(eng, g, meta, loss, logits, plan, full=True, loss_tol=5e-3):
     worst = 0.0
     for k, want in meta["grad_norms"].items():
         if want is None:
+            if k in eng.lm.offsets:   # trainable here but unused by the graph (last ViT layer): exactly zero
+                assert float(eng.G(k).float().abs().max()) == 0.0, k
             continue
         got = float(eng.G(k).float().norm())
         rel = abs(got - want) / max(want, 1e-6)
         worst = max(worst, rel)
-        assert rel < 5e-2, (k, got, want)
+        # 5 % relative, with an absolute floor for gradients that are mathematically zero (e.g. CLIP k_proj.bias:
+        # softmax is invariant to a key bias; the reference holds 1e-11 there, bf16 arithmetic 1e-7)
+        assert abs(got - want) < 5e-2 * want + 1e-5, (k, got, want)
     for k in g.files:
         if k.startswith("grad::"):
             ref = torch.from_numpy(g[k])
@@ -84,6 +88,17 @@ def test_toy_anyres_unpad(golden_dir):
     sizes = [tuple(s) for s in g["image_sizes"].tolist()]
     loss, logits, plan = _run(eng, g, images, sizes)
     _check(eng, g, meta, loss, logits, plan)
+
+
+def test_toy_vision_tower_tunable(golden_dir):
+    """mm_tunable_parts = mm_vision_tower,mm_mlp_adapter,mm_language_model (the RadVLM recipe): ViT backward."""
+    g, meta, images = _golden(golden_dir, "toy_tower_e2e")
+    eng = _engine("toy", train_vision_tower=True)
+    loss, logits, plan = _run(eng, g, images)
+    _check(eng, g, meta, loss, logits, plan)
+    eng.optimizer_step(lr=1e-3, max_grad_norm=1.0, mm_vision_tower_lr=2e-4)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(eng.lm.flat.float()).all())
 
 
 def test_config1(golden_dir):

@@ -116,6 +116,29 @@ def test_layernorm(ops):
     assert relerr(ops.layernorm_fwd(x.cuda(), w.cuda(), b.cuda()), ref) < TOL
 
 
+def test_layernorm_bwd_and_quick_gelu(ops):
+    from oracle import llava_oracle as O
+    rows, d = 45, 1024
+    x, w, b, dy = rnd(50, (rows, d)), (1 + rnd(51, (d,), 0.1).float()).to(torch.bfloat16), rnd(52, (d,), 0.1), rnd(53, (rows, d))
+    xr, wr, br = x.float().requires_grad_(True), w.float().requires_grad_(True), b.float().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xr, (d,), wr, br, 1e-5)
+    y.backward(dy.float())
+    yg, st = ops.layernorm_fwd(x.cuda(), w.cuda(), b.cuda(), save_stats=True)
+    assert relerr(yg, y) < TOL
+    dw, db = torch.zeros(d, dtype=torch.bfloat16, device="cuda"), torch.zeros(d, dtype=torch.bfloat16, device="cuda")
+    dx = ops.layernorm_bwd(dy.cuda(), x.cuda(), w.cuda(), st, dw, db)
+    assert relerr(dx, xr.grad) < TOL and relerr(dw, wr.grad) < TOL and relerr(db, br.grad) < TOL
+    dx2 = dx.clone()
+    ops.layernorm_bwd(dy.cuda(), x.cuda(), w.cuda(), st, dw, db, dx=dx2, dx_add=True, accumulate=True)
+    assert relerr(dx2, 2 * xr.grad) < 2 * TOL and relerr(dw, 2 * wr.grad) < 2 * TOL
+    z, dz = rnd(54, (40, 256)), rnd(55, (40, 256))
+    zr = z.float().requires_grad_(True)
+    q = O.quick_gelu(zr)
+    q.backward(dz.float())
+    assert relerr(ops.quick_gelu_fwd(z.cuda()), q) < TOL
+    assert relerr(ops.quick_gelu_bwd(dz.cuda(), z.cuda()), zr.grad) < TOL
+
+
 def test_rope(ops):
     from oracle import llava_oracle as O
     B, S, H, hd = 2, 40, 2, 128

@@ -100,13 +100,13 @@ def test_host_functions(golden_dir):
         assert O.tokenizer_image_token(prompt, Tok()) == want
 
 
-def _run_e2e(golden_dir, name, with_newline=False):
+def _run_e2e(golden_dir, name, with_newline=False, tower_grads=False):
     g = _load(golden_dir, name + ".npz")
     meta = json.load(open(os.path.join(golden_dir, name + "_gradnorms.json")))
     geo = GEOMETRIES[meta["geometry"]]
     P = O.make_params(geo, seed=0, with_newline=with_newline)
     for k, v in P.items():
-        if "vision_tower" not in k:
+        if tower_grads or "vision_tower" not in k:
             v.requires_grad_(True)
     nimg = len([k for k in g.files if k.startswith("image") and k[5:].isdigit()])
     images = [torch.from_numpy(g[f"image{i}"]) for i in range(nimg)]
@@ -152,6 +152,15 @@ def test_e2e_toy_anyres(golden_dir):
     m = _check_common(g, meta, P, loss, logits, aux)
     assert _maxrel(aux["inputs_embeds"].detach(), g["inputs_embeds"]) < 1e-5
     assert _maxrel(logits.detach().numpy()[m], g["logits"][m]) < 1e-4
+
+
+def test_e2e_toy_tower_unfrozen(golden_dir):
+    """mm_tunable_parts with mm_vision_tower: tower gradients; the unused last layer / post_layernorm get none."""
+    g, meta, P, loss, logits, aux = _run_e2e(golden_dir, "toy_tower_e2e", tower_grads=True)
+    _check_common(g, meta, P, loss, logits, aux)
+    for k in g.files:
+        if k.startswith("grad::"):
+            assert _maxrel(P[k[6:]].grad, g[k]) < 1e-4, k
 
 
 @pytest.mark.slow
