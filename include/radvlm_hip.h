@@ -39,10 +39,11 @@ int rv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void
  * Lets the autograd GEMMs read their operands in place (hardware-transposed LDS reads, ds_read_b64_tr_b16):
  *   dgrad dX[M,Kin] = dY[M,Nout] * W[Nout,Kin]        -> trans_b (W is [contraction, Kin]);
  *   wgrad dW[Nout,Kin] = dY[M,Nout]^T * X[M,Kin]      -> trans_a and trans_b (both are [contraction=tokens, features]).
- * Feature dimensions of transposed operands must be multiples of 8. */
+ * Feature dimensions of transposed operands must be multiples of 8.  C = act(alpha * op(A) op(B)^T + bias) + residual;
+ * alpha carries the LoRA scaling lora_alpha / r (peft LoraLayer, train/train.py:1515-1532). */
 int rv_gemm_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
-                 const void* residual, int64_t ldr, int M, int N, int K, int trans_a, int trans_b, int act, int out_f32,
-                 int res_f32, const void* zeros16, void* stream);
+                 const void* residual, int64_t ldr, int M, int N, int K, int trans_a, int trans_b, float alpha, int act,
+                 int out_f32, int res_f32, const void* zeros16, void* stream);
 /* Tuning hook: 0 = automatic tile selection (default), 1 = 128x128 tile kernel, 2 = 256x256 tile kernel. */
 int rv_gemm_select_kernel(int which);
 
@@ -106,6 +107,9 @@ int rv_attn_bwd(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const 
 int rv_swiglu_fwd(const void* gu, int64_t ld_gu, void* act, int64_t ld_act, int rows, int F, void* stream);
 int rv_swiglu_bwd(const void* dact, int64_t ld_dact, const void* gu, int64_t ld_gu, void* dgu, int64_t ld_dgu, int rows,
                   int F, void* stream);
+/* Inverted dropout with a counter-based mask: y[i] = keep(seed, i) ? x[i] / (1 - p) : 0, keep = hash(seed, i) >= p.
+ * The same (seed, p) regenerates the mask, so backward applies the same call to the gradient (lora_dropout). */
+int rv_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, void* stream);
 /* torch.nn.GELU (erf) of the mm_projector (multimodal_projector/builder.py:44) and its derivative. */
 int rv_gelu_fwd(const void* x, void* y, int64_t n, void* stream);
 int rv_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);

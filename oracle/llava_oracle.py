@@ -367,6 +367,24 @@ def llava_forward(P, geo, input_ids, attention_mask, labels, images, image_sizes
     return loss, logits, dict(inputs_embeds=E, labels=L, attention_mask=M, lens=lens, image_features=feats)
 
 
+# ----------------------------------------------------------------------------- LoRA
+LORA_TARGETS = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj",
+                "mlp.down_proj")
+
+
+def apply_lora(P, L, geo, scale):
+    """peft 0.4.0 LoraLayer at dropout 0 (train/train.py:1515-1532 wires r=64, alpha=16 on every LM linear except
+    lm_head, :242-255): y = x W^T + (alpha/r) x A^T B^T  ==  x (W + (alpha/r) B A)^T.  peft is not installed here and the
+    reference holds no LoRA fixtures: PARITY UNPINNED for this function (restated from the published formula).
+    Returns a parameter dict with the effective weights; autograd reaches A and B through it."""
+    out = dict(P)
+    for i in range(geo["lm"]["layers"]):
+        for t in LORA_TARGETS:
+            n = f"model.layers.{i}.{t}."
+            out[n + "weight"] = P[n + "weight"] + scale * (L[n + "lora_B.weight"] @ L[n + "lora_A.weight"])
+    return out
+
+
 # ----------------------------------------------------------------------------- optimizer (torch.optim.AdamW semantics)
 def adamw_step(p, g, m, v, step, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.0):
     """torch.optim.AdamW single-tensor update (optim='adamw_torch', train/train.py:140), fp32, in place."""

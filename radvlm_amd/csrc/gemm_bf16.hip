@@ -25,6 +25,7 @@ struct GemmParams {
     const bf16* A; const bf16* B; void* C; const bf16* bias; const void* R; const bf16* zeros;
     long lda, ldb, ldc, ldr;
     int M, N, K, act, out_f32, res_f32, tiles_m, tiles_n;
+    float alpha;
 };
 
 DEVINL float apply_act(float x, int act) {
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams P) {
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wc * 64 + j * 16 + 4 * (lane >> 4);
             if (n >= P.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            float v[4] = {acc[i][j][0] * P.alpha, acc[i][j][1] * P.alpha, acc[i][j][2] * P.alpha, acc[i][j][3] * P.alpha};
             const int nv = min(4, P.N - n);
             if (P.bias) {
 #pragma unroll
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wc * 64 + j * 16 + 4 * (lane >> 4);
             if (n >= P.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            float v[4] = {acc[i][j][0] * P.alpha, acc[i][j][1] * P.alpha, acc[i][j][2] * P.alpha, acc[i][j][3] * P.alpha};
             const int nv = min(4, P.N - n);
             if (P.bias) {
 #pragma unroll
@@ -426,8 +427,8 @@ static void launch256(const GemmParams& P, hipStream_t st) {
 }
 
 extern "C" int rv_gemm_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
-                            const void* residual, int64_t ldr, int M, int N, int K, int trans_a, int trans_b, int act,
-                            int out_f32, int res_f32, const void* zeros16, void* stream) {
+                            const void* residual, int64_t ldr, int M, int N, int K, int trans_a, int trans_b, float alpha,
+                            int act, int out_f32, int res_f32, const void* zeros16, void* stream) {
     if (!A || !B || !C || !zeros16 || M <= 0 || N <= 0 || K <= 0) return RV_ERR_ARG;
     if ((lda & 7) || (ldb & 7)) return RV_ERR_ARG;
     if ((!trans_a && (K & 7)) || (trans_a && (M & 7)) || (!trans_b && (K & 7)) || (trans_b && (N & 7))) return RV_ERR_ARG;
@@ -436,7 +437,7 @@ extern "C" int rv_gemm_bf16(const void* A, int64_t lda, const void* B, int64_t l
     P.A = (const bf16*)A; P.B = (const bf16*)B; P.C = C; P.bias = (const bf16*)bias; P.R = residual;
     P.zeros = (const bf16*)zeros16;
     P.lda = lda; P.ldb = ldb; P.ldc = ldc; P.ldr = ldr;
-    P.M = M; P.N = N; P.K = K; P.act = act; P.out_f32 = out_f32; P.res_f32 = res_f32;
+    P.M = M; P.N = N; P.K = K; P.act = act; P.out_f32 = out_f32; P.res_f32 = res_f32; P.alpha = alpha;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES);
@@ -463,5 +464,5 @@ extern "C" int rv_gemm_bf16(const void* A, int64_t lda, const void* B, int64_t l
 extern "C" int rv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
                                const void* bias, const void* residual, int64_t ldr, int M, int N, int K, int act,
                                int out_f32, int res_f32, const void* zeros16, void* stream) {
-    return rv_gemm_bf16(A, lda, B, ldb, C, ldc, bias, residual, ldr, M, N, K, 0, 0, act, out_f32, res_f32, zeros16, stream);
+    return rv_gemm_bf16(A, lda, B, ldb, C, ldc, bias, residual, ldr, M, N, K, 0, 0, 1.0f, act, out_f32, res_f32, zeros16, stream);
 }

@@ -327,6 +327,22 @@ __global__ void swiglu_bwd_kernel(const bf16* dact, long ld_dact, const bf16* gu
     st8(dgu + r * ld_dgu + F + f, du);
 }
 
+DEVINL unsigned hash32(unsigned long long seed, unsigned long long i) {
+    unsigned long long z = (i + seed * 0x9E3779B97F4A7C15ull) + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (unsigned)((z ^ (z >> 31)) >> 32);
+}
+__global__ void dropout_kernel(const bf16* x, bf16* y, long n8, unsigned thr, float scale, unsigned long long seed) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    float v[8], o[8];
+    ld8(x + i * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = hash32(seed, (unsigned long long)(i * 8 + j)) >= thr ? v[j] * scale : 0.f;
+    st8(y + i * 8, o);
+}
+
 __global__ void gelu_fwd_kernel(const bf16* x, bf16* y, long n8) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n8) return;
@@ -670,6 +686,12 @@ extern "C" int rv_swiglu_fwd(const void* gu, int64_t ld_gu, void* act, int64_t l
 extern "C" int rv_swiglu_bwd(const void* dact, int64_t ld_dact, const void* gu, int64_t ld_gu, void* dgu, int64_t ld_dgu, int rows, int F, void* stream) {
     if (!dact || !gu || !dgu || rows <= 0 || (F & 7) || (ld_gu & 7) || (ld_dact & 7) || (ld_dgu & 7)) return RV_ERR_ARG;
     hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(nblocks((long)rows * (F / 8), 256)), dim3(256), 0, ST, (const bf16*)dact, (long)ld_dact, (const bf16*)gu, (long)ld_gu, (bf16*)dgu, (long)ld_dgu, rows, F);
+    return rv_check_launch();
+}
+extern "C" int rv_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, void* stream) {
+    if (!x || !y || n <= 0 || (n & 7) || p < 0.f || p >= 1.f) return RV_ERR_ARG;
+    const unsigned thr = (unsigned)((double)p * 4294967296.0);
+    hipLaunchKernelGGL(dropout_kernel, dim3(nblocks(n / 8, 256)), dim3(256), 0, ST, (const bf16*)x, (bf16*)y, (long)(n / 8), thr, 1.f / (1.f - p), (unsigned long long)seed);
     return rv_check_launch();
 }
 extern "C" int rv_gelu_fwd(const void* x, void* y, int64_t n, void* stream) {

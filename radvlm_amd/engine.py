@@ -19,7 +19,8 @@ import numpy as np
 import torch
 
 from . import ops
-from .params import VP, FlatParams, fast_random_init_, lm_param_shapes, portable_init_, vision_param_shapes
+from .params import (LORA_TARGETS, VP, FlatParams, fast_random_init_, lm_param_shapes, lora_trainable_shapes, portable_init_,
+                     vision_param_shapes)
 from .splice import build_splice_plan, merged_feature_rows, shifted_labels
 
 BF16 = torch.bfloat16
@@ -32,7 +33,7 @@ def _ru(x, m):
 class LlavaEngine:
     def __init__(self, geo, device="cuda", merge_type="flat", image_aspect_ratio="square", image_grid_pinpoints=None,
                  max_len=None, init="portable", seed=0, rms_eps=1e-5, rope_theta=10000.0, process_group=None,
-                 bucket_layers=1, train_vision_tower=False):
+                 bucket_layers=1, train_vision_tower=False, lora=None):
         self.geo = geo
         self.v, self.l = geo["vision"], geo["lm"]
         self.device = torch.device(device)
@@ -47,7 +48,19 @@ class LlavaEngine:
         self.P = self.side * self.side
         self.kp = _ru(3 * self.v["patch"] ** 2, 8)
         self.train_tower = train_vision_tower
-        if train_vision_tower:
+        self.lora = dict(lora) if lora else None   # {"r": 64, "alpha": 16, "dropout": 0.05}
+        self.base = None
+        if self.lora:
+            # LoRA (BASELINE config 5): the language model is a frozen bf16 store; only adapters + projector are
+            # trainable, so gradients / AdamW state / the DP all-reduce cover ~2 % of the parameters
+            assert not train_vision_tower
+            r = self.lora["r"]
+            self.lora_scale = self.lora.get("alpha", 16) / r
+            self.lora_p = float(self.lora.get("dropout", 0.0))
+            self.base = FlatParams(lm_param_shapes(geo, False), self.device)
+            self.lm = FlatParams(lora_trainable_shapes(geo, r, self.with_newline), self.device)
+            self.vis = FlatParams(vision_param_shapes(geo), self.device)
+        elif train_vision_tower:
             # mm_tunable_parts contains mm_vision_tower (train/train.py:1658-1661): the tower joins the trainable flat
             # buffer, in front (forward order), so its gradients are the last bucket of the backward pass
             from collections import OrderedDict
@@ -59,14 +72,21 @@ class LlavaEngine:
             self.lm = FlatParams(lm_param_shapes(geo, self.with_newline), self.device)
             self.vis = FlatParams(vision_param_shapes(geo), self.device)
         self.grads = self.lm.like(BF16)
-        if init == "portable":
-            portable_init_(self.lm, self.l["d"], seed)
-            if not train_vision_tower:
-                portable_init_(self.vis, self.l["d"], seed)
-        elif init == "fast":
-            fast_random_init_(self.lm, self.l["d"], seed)
-            if not train_vision_tower:
-                fast_random_init_(self.vis, self.l["d"], seed + 1)
+        stores = [self.lm] + ([] if train_vision_tower else [self.vis]) + ([self.base] if self.base is not None else [])
+        for k, st in enumerate(stores):
+            if init == "portable":
+                portable_init_(st, self.l["d"], seed)
+            elif init == "fast":
+                fast_random_init_(st, self.l["d"], seed + k)
+        if self.lora and init in ("portable", "fast"):
+            # the projector and the frozen base keep the names (hence values) of the full model; adapters: peft init
+            for n in self.lm.names():
+                if n.endswith("lora_B.weight"):
+                    self.lm.view(n).zero_()
+                elif n.endswith("lora_A.weight") and init == "fast":
+                    bound = 1.0 / math.sqrt(self.lm.shapes[n][1])   # kaiming_uniform(a=sqrt(5)) of peft's lora_A
+                    self.lm.view(n).copy_((torch.rand(self.lm.shapes[n], device=self.device) * 2 - 1) * bound)
+        self.lora_step = 0
         self._patch_w = None
         self._rope = {}
         self.master = self.m = self.vv = None
@@ -82,7 +102,9 @@ class LlavaEngine:
 
     # ------------------------------------------------------------------ weights
     def W(self, name):
-        return self.lm.view(name)
+        if name in self.lm.offsets:
+            return self.lm.view(name)
+        return self.base.view(name)
 
     def G(self, name):
         return self.lm.view(name, self.grads)
@@ -91,6 +113,10 @@ class LlavaEngine:
         d, F = self.l["d"], self.l["ffn"]
         p = f"model.layers.{i}."
         f = self.lm
+        if self.base is not None:
+            if flat is not None:
+                return {}          # the base weights of a LoRA run have no gradients
+            f = self.base
         return dict(
             ln1=f.view(p + "input_layernorm.weight", flat),
             qkv=f.fused(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", 3 * d, d, flat),
@@ -264,6 +290,7 @@ class LlavaEngine:
         d, F, H, V, L = l["d"], l["ffn"], l["heads"], l["vocab"], l["layers"]
         hd = d // H
         plan = self.plan(input_ids, attention_mask, labels, images, image_sizes)
+        self.lora_step += 1
         pix = torch.cat([(im if im.ndim == 4 else im[None]) for im in images], 0)
         pix = pix.to(dev, non_blocking=True)
         pix = pix if pix.dtype == BF16 else ops.to_bf16(pix.float())
@@ -281,17 +308,26 @@ class LlavaEngine:
         for i in range(L):
             lv = self._layer_views(i)
             h1, rstd1 = ops.rmsnorm_fwd(x, lv["ln1"], self.eps)
+            sv = {}
             qkv = ops.gemm_nt(h1, lv["qkv"])
+            if self.lora:
+                self._lora_fwd(h1, qkv, i, (("self_attn.q_proj", 0, d), ("self_attn.k_proj", d, 2 * d), ("self_attn.v_proj", 2 * d, 3 * d)), sv)
             ops.rope_inplace(qkv, cs, S, H, hd, 2, 1)
             vT = ops.transpose_heads(qkv[:, 2 * d:], B, S, H, hd, s_pad)
             attn, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], vT, B, S, H, hd, s_pad, causal=True, lens=lens)
             x_mid = ops.gemm_nt(attn, lv["o"], residual=x)
+            if self.lora:
+                self._lora_fwd(attn, x_mid, i, (("self_attn.o_proj", 0, d),), sv)
             h2, rstd2 = ops.rmsnorm_fwd(x_mid, lv["ln2"], self.eps)
             gu = ops.gemm_nt(h2, lv["gu"])
+            if self.lora:
+                self._lora_fwd(h2, gu, i, (("mlp.gate_proj", 0, F), ("mlp.up_proj", F, 2 * F)), sv)
             act = ops.swiglu_fwd(gu, F)
             x_out = ops.gemm_nt(act, lv["down"], residual=x_mid)
+            if self.lora:
+                self._lora_fwd(act, x_out, i, (("mlp.down_proj", 0, d),), sv)
             layers.append(dict(x=x, rstd1=rstd1, h1=h1, qkv=qkv, attn=attn, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2,
-                               gu=gu, act=act))
+                               gu=gu, act=act, lora=sv))
             x = x_out
         hN, rstdN = ops.rmsnorm_fwd(x, self.W("model.norm.weight"), self.eps)
         logits = ops.gemm_nt(hN, self.W("lm_head.weight"))
@@ -321,12 +357,58 @@ class LlavaEngine:
     # ------------------------------------------------------------------ backward
     def _linear_bwd(self, dy, x, w, gw, need_dx=True, dx_out=None):
         """Backward of y = x W^T:  dW[N,K] = dY^T X  (both operands read contraction-major, in place) into the flat
-        grad view, and dX[M,K] = dY W (W read contraction-major) -- no transposed copies of weights or activations."""
+        grad view (skipped when gw is None: frozen weight), and dX[M,K] = dY W (W read contraction-major) -- no
+        transposed copies of weights or activations."""
         acc = self.grad_accum_started
-        ops.gemm(dy, x, ta=True, tb=True, out=gw, residual=gw if acc else None)
+        if gw is not None:
+            ops.gemm(dy, x, ta=True, tb=True, out=gw, residual=gw if acc else None)
         if need_dx:
             return ops.gemm(dy, w, tb=True, out=dx_out)
         return None
+
+    # ------------------------------------------------------------------ LoRA (peft LoraLayer semantics, train.py:1515-1532)
+    def _lora_seed(self, i, lname):
+        k = [t for t, _, _ in LORA_TARGETS].index(lname)
+        return (self.lora_step * 1000003 + i * 131 + k) & 0x7FFFFFFFFFFFFFFF
+
+    def _lora_fwd(self, x, y, i, mods, saved):
+        """y[:, c0:c1] += (alpha/r) * dropout(x) A^T B^T for every adapted module writing columns [c0, c1) of y."""
+        for lname, c0, c1 in mods:
+            pre = f"model.layers.{i}.{lname}."
+            A, B = self.W(pre + "lora_A.weight"), self.W(pre + "lora_B.weight")
+            xd = ops.dropout(x, self.lora_p, self._lora_seed(i, lname)) if self.lora_p > 0 else x
+            t = ops.gemm_nt(xd, A)
+            ys = y[:, c0:c1]
+            ops.gemm(t, B, out=ys, residual=ys, alpha=self.lora_scale)
+            saved[lname] = t
+
+    def _lora_bwd(self, dy, x, i, mods, saved, dx):
+        """Adapter gradients and the adapter path's contribution to dx (dx already holds dY W of the frozen weight)."""
+        acc = self.grad_accum_started
+        for lname, c0, c1 in mods:
+            pre = f"model.layers.{i}.{lname}."
+            A, B = self.W(pre + "lora_A.weight"), self.W(pre + "lora_B.weight")
+            gA, gB = self.G(pre + "lora_A.weight"), self.G(pre + "lora_B.weight")
+            dyj = dy[:, c0:c1]
+            t = saved[lname]
+            dt = ops.gemm(dyj, B, tb=True, alpha=self.lora_scale)
+            ops.gemm(dyj, t, ta=True, tb=True, out=gB, residual=gB if acc else None, alpha=self.lora_scale)
+            if self.lora_p > 0:
+                seed = self._lora_seed(i, lname)
+                xd = ops.dropout(x, self.lora_p, seed)
+                ops.gemm(dt, xd, ta=True, tb=True, out=gA, residual=gA if acc else None)
+                tmp = ops.dropout(ops.gemm(dt, A, tb=True), self.lora_p, seed)
+                from . import lib
+                lib.call("rv_add_bf16", dx, tmp, dx, dx.numel())
+            else:
+                ops.gemm(dt, x, ta=True, tb=True, out=gA, residual=gA if acc else None)
+                ops.gemm(dt, A, tb=True, out=dx, residual=dx)
+
+    def _lm_linear_bwd(self, dy, x, w, gw, i, mods, saved):
+        dx = self._linear_bwd(dy, x, w, None if self.lora else gw)
+        if self.lora:
+            self._lora_bwd(dy, x, i, mods, saved, dx)
+        return dx
 
     def backward(self):
         """Backward of the last forward(); gradients land in self.grads (bf16, flat)."""
@@ -339,29 +421,36 @@ class LlavaEngine:
         acc = self.grad_accum_started
         cs = self.rope_table(S)
         # head
-        dhN = self._linear_bwd(c["dlogits"], c["hN"], self.W("lm_head.weight"), self.G("lm_head.weight"))
-        dx, _ = ops.rmsnorm_bwd(dhN, c["x_last"], self.W("model.norm.weight"), c["rstdN"], dw=self.G("model.norm.weight"),
-                                dw_accumulate=acc)
-        self._bucket_done("lm_head.weight", "lm_head.weight")
-        self._bucket_done("model.norm.weight", "model.norm.weight")
+        frozen_lm = self.lora is not None
+        dhN = self._linear_bwd(c["dlogits"], c["hN"], self.W("lm_head.weight"), None if frozen_lm else self.G("lm_head.weight"))
+        dx, _ = ops.rmsnorm_bwd(dhN, c["x_last"], self.W("model.norm.weight"), c["rstdN"],
+                                dw=None if frozen_lm else self.G("model.norm.weight"), dw_accumulate=acc)
+        if not frozen_lm:
+            self._bucket_done("lm_head.weight", "lm_head.weight")
+            self._bucket_done("model.norm.weight", "model.norm.weight")
         for i in reversed(range(L)):
             a = c["layers"][i]
             lv, gv = self._layer_views(i), self._layer_views(i, self.grads)
-            dact = self._linear_bwd(dx, a["act"], lv["down"], gv["down"])
+            sv = a["lora"]
+            dact = self._lm_linear_bwd(dx, a["act"], lv["down"], gv.get("down"), i, (("mlp.down_proj", 0, d),), sv)
             dgu = ops.swiglu_bwd(dact, a["gu"], F)
-            dh2 = self._linear_bwd(dgu, a["h2"], lv["gu"], gv["gu"])
-            ops.rmsnorm_bwd(dh2, a["x_mid"], lv["ln2"], a["rstd2"], dx=dx, dx_add=True, dw=gv["ln2"], dw_accumulate=acc)
-            dattn = self._linear_bwd(dx, a["attn"], lv["o"], gv["o"])
+            dh2 = self._lm_linear_bwd(dgu, a["h2"], lv["gu"], gv.get("gu"), i, (("mlp.gate_proj", 0, F), ("mlp.up_proj", F, 2 * F)), sv)
+            ops.rmsnorm_bwd(dh2, a["x_mid"], lv["ln2"], a["rstd2"], dx=dx, dx_add=True, dw=gv.get("ln2"), dw_accumulate=acc)
+            dattn = self._lm_linear_bwd(dx, a["attn"], lv["o"], gv.get("o"), i, (("self_attn.o_proj", 0, d),), sv)
             qkv = a["qkv"]
             dqkv = torch.empty_like(qkv)
             ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a["attn"], dattn, a["lse"], B, S, H, hd, s_pad, True,
                          lens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:])
             ops.rope_inplace(dqkv, cs, S, H, hd, 2, -1)
-            dh1 = self._linear_bwd(dqkv, a["h1"], lv["qkv"], gv["qkv"])
-            ops.rmsnorm_bwd(dh1, a["x"], lv["ln1"], a["rstd1"], dx=dx, dx_add=True, dw=gv["ln1"], dw_accumulate=acc)
+            dh1 = self._lm_linear_bwd(dqkv, a["h1"], lv["qkv"], gv.get("qkv"), i,
+                                      (("self_attn.q_proj", 0, d), ("self_attn.k_proj", d, 2 * d), ("self_attn.v_proj", 2 * d, 3 * d)), sv)
+            ops.rmsnorm_bwd(dh1, a["x"], lv["ln1"], a["rstd1"], dx=dx, dx_add=True, dw=gv.get("ln1"), dw_accumulate=acc)
             c["layers"][i] = None  # free this layer's activations
             p = f"model.layers.{i}."
-            self._bucket_done(p + "input_layernorm.weight", p + "mlp.down_proj.weight")
+            if frozen_lm:
+                self._bucket_done(p + "self_attn.q_proj.lora_A.weight", p + "mlp.down_proj.lora_B.weight")
+            else:
+                self._bucket_done(p + "input_layernorm.weight", p + "mlp.down_proj.weight")
         # dx = gradient of inputs_embeds [M, d]
         plan = c["plan"]
         dev = self.device
@@ -387,8 +476,10 @@ class LlavaEngine:
                                      torch.from_numpy(npos).to(dev), torch.zeros(1, dtype=torch.int32, device=dev), tmp)
                 gn.add_(tmp) if acc else gn.copy_(tmp)
         # embedding rows: segment sums by token id (no atomics)
-        ge = g("model.embed_tokens.weight")
-        if acc:
+        ge = g("model.embed_tokens.weight") if not frozen_lm else None
+        if frozen_lm:
+            pass
+        elif acc:
             tmp = torch.zeros_like(ge)
             ops.segment_sum_rows(dx, torch.from_numpy(plan["tok_off"]).to(dev), torch.from_numpy(plan["tok_pos"]).to(dev),
                                  torch.from_numpy(plan["tok_ids"]).to(dev), tmp)
@@ -398,7 +489,7 @@ class LlavaEngine:
             ops.segment_sum_rows(dx, torch.from_numpy(plan["tok_off"]).to(dev), torch.from_numpy(plan["tok_pos"]).to(dev),
                                  torch.from_numpy(plan["tok_ids"]).to(dev), ge)
         last = "model.image_newline" if self.with_newline else "model.mm_projector.2.bias"
-        self._bucket_done("model.embed_tokens.weight", last)
+        self._bucket_done("model.mm_projector.0.weight" if frozen_lm else "model.embed_tokens.weight", last)
         if self.train_tower:
             n_img = c["v_n"]
             N = self.P + 1
@@ -476,6 +567,18 @@ class LlavaEngine:
             for n in fp.names():
                 out[n] = fp.view(n)
         return out
+
+    def lora_state_dict(self):
+        """Adapter tensors under peft's key layout (base_model.model.<module>.lora_{A,B}.default.weight) + the
+        non-LoRA trainables (the reference saves them as non_lora_trainables.bin, train/train.py:1708-1717)."""
+        assert self.lora
+        adapters, others = {}, {}
+        for n in self.lm.names():
+            if ".lora_" in n:
+                adapters["base_model.model." + n.replace(".weight", ".default.weight")] = self.lm.view(n)
+            else:
+                others[n] = self.lm.view(n)
+        return adapters, others
 
     def load_state_dict(self, sd, strict=False):
         from .params import load_named

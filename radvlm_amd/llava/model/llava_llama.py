@@ -19,7 +19,7 @@ class LlavaConfig:
     model_type = "llava_llama"
 
     def __init__(self, geometry=None, mm_patch_merge_type="flat", image_aspect_ratio="square", image_grid_pinpoints=None,
-                 tokenizer_model_max_length=None, rms_norm_eps=1e-5, rope_theta=10000.0, unfreeze_mm_vision_tower=False, **kw):
+                 tokenizer_model_max_length=None, rms_norm_eps=1e-5, rope_theta=10000.0, unfreeze_mm_vision_tower=False, lora=None, **kw):
         from ...config import GEOMETRIES
         self.geometry = geometry or GEOMETRIES["llava15_7b"]
         l, v = self.geometry["lm"], self.geometry["vision"]
@@ -39,6 +39,7 @@ class LlavaConfig:
         self.use_cache = False
         self.use_mm_proj = True
         self.unfreeze_mm_vision_tower = unfreeze_mm_vision_tower
+        self.lora = lora   # {'r', 'alpha', 'dropout'} or None
         for k, val in kw.items():
             setattr(self, k, val)
 
@@ -142,7 +143,8 @@ class LlavaLlamaForCausalLM:
                                   image_aspect_ratio=config.image_aspect_ratio, image_grid_pinpoints=config.image_grid_pinpoints,
                                   max_len=config.tokenizer_model_max_length, init=init, seed=seed, rms_eps=config.rms_norm_eps,
                                   rope_theta=config.rope_theta, process_group=process_group,
-                                  train_vision_tower=getattr(config, "unfreeze_mm_vision_tower", False))
+                                  train_vision_tower=getattr(config, "unfreeze_mm_vision_tower", False),
+                                  lora=getattr(config, "lora", None))
         self.model = LlavaLlamaModel(self.engine, config)
         self.training = True
         # a leaf that makes loss require grad so that `.backward()` reaches the engine
@@ -206,5 +208,10 @@ class LlavaLlamaForCausalLM:
     def save_pretrained(self, out_dir):
         from safetensors.torch import save_file
         os.makedirs(out_dir, exist_ok=True)
+        if self.engine.lora:
+            adapters, others = self.engine.lora_state_dict()   # reference: adapter weights + non_lora_trainables (train.py:1708-1717)
+            save_file({k: v.detach().clone().contiguous().cpu() for k, v in adapters.items()}, os.path.join(out_dir, "adapter_model.safetensors"))
+            save_file({k: v.detach().clone().contiguous().cpu() for k, v in others.items()}, os.path.join(out_dir, "non_lora_trainables.safetensors"))
+            return
         sd = {k: v.detach().clone().contiguous().cpu() for k, v in self.engine.state_dict().items()}
         save_file(sd, os.path.join(out_dir, "model.safetensors"))

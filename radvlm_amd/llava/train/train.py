@@ -486,13 +486,16 @@ def train(attn_implementation=None, argv=None, tokenizer=None):
     parts = tunable_parts(model_args)
     if parts - {"mm_vision_tower"} != {"mm_mlp_adapter", "mm_language_model"}:
         raise NotImplementedError(f"tunable parts {sorted(parts)}: the projector and the language model are always trained here")
-    if training_args.lora_enable:
-        raise NotImplementedError("LoRA (BASELINE config 5) is scheduled after the full fine-tune path (SURVEY 8f)")
+    lora = None
+    if training_args.lora_enable:   # peft LoraConfig(r, lora_alpha, lora_dropout, bias="none") on every LM linear (train.py:1515-1532)
+        if training_args.lora_bias != "none" or "mm_vision_tower" in parts:
+            raise NotImplementedError("lora_bias != 'none' / LoRA together with a tunable vision tower")
+        lora = dict(r=training_args.lora_r, alpha=training_args.lora_alpha, dropout=training_args.lora_dropout)
     name = model_args.geometry or ("llava15_13b" if "13b" in (model_args.model_name_or_path or "").lower() else "llava15_7b")
     cfg = LlavaConfig(geometry=GEOMETRIES[name], mm_patch_merge_type=model_args.mm_patch_merge_type,
                       image_aspect_ratio=data_args.image_aspect_ratio, image_grid_pinpoints=data_args.image_grid_pinpoints,
                       tokenizer_model_max_length=training_args.model_max_length,
-                      unfreeze_mm_vision_tower="mm_vision_tower" in parts)
+                      unfreeze_mm_vision_tower="mm_vision_tower" in parts, lora=lora)
     model = LlavaLlamaForCausalLM(cfg, device=f"cuda:{local}", process_group=pg, init="fast")
     model.config.use_cache = False
     model.get_model().initialize_vision_modules(model_args)

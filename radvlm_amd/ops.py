@@ -44,7 +44,7 @@ def gemm_nt(a, b, out=None, bias=None, residual=None, act=ACT_NONE, out_dtype=BF
     return out
 
 
-def gemm(a, b, ta=False, tb=False, out=None, bias=None, residual=None, act=ACT_NONE, out_dtype=BF16):
+def gemm(a, b, ta=False, tb=False, out=None, bias=None, residual=None, act=ACT_NONE, out_dtype=BF16, alpha=1.0):
     """out[M,N] = act(op(a) @ op(b)^T + bias) + residual with a stored [K,M] if ta else [M,K], b stored [K,N] if tb else [N,K]."""
     _chk(a), _chk(b)
     assert a.stride(1) == 1 and b.stride(1) == 1
@@ -61,7 +61,7 @@ def gemm(a, b, ta=False, tb=False, out=None, bias=None, residual=None, act=ACT_N
     if bias is not None:
         assert bias.numel() == N and bias.is_contiguous()
     lib.call("rv_gemm_bf16", a, a.stride(0), b, b.stride(0), out, out.stride(0), bias, residual, ldr, M, N, K, int(ta), int(tb),
-             act, int(out.dtype == torch.float32), res_f32, lib.zeros16(a.device))
+             float(alpha), act, int(out.dtype == torch.float32), res_f32, lib.zeros16(a.device))
     return out
 
 
@@ -229,6 +229,14 @@ def swiglu_bwd(dact, gu, F, dgu=None):
     dgu = torch.empty_like(gu) if dgu is None else dgu
     lib.call("rv_swiglu_bwd", dact, dact.stride(0), gu, gu.stride(0), dgu, dgu.stride(0), rows, F)
     return dgu
+
+
+def dropout(x, p, seed, y=None):
+    """Inverted dropout with a regenerable counter-based mask (same (p, seed) in backward)."""
+    assert x.is_contiguous()
+    y = torch.empty_like(x) if y is None else y
+    lib.call("rv_dropout_bf16", x, y, x.numel(), float(p), int(seed))
+    return y
 
 
 def gelu_fwd(x, y=None):

@@ -52,6 +52,29 @@ def lm_param_shapes(geo, with_newline=False):
     return s
 
 
+LORA_TARGETS = (("self_attn.q_proj", "d", "d"), ("self_attn.k_proj", "d", "d"), ("self_attn.v_proj", "d", "d"),
+                ("self_attn.o_proj", "d", "d"), ("mlp.gate_proj", "ffn", "d"), ("mlp.up_proj", "ffn", "d"),
+                ("mlp.down_proj", "d", "ffn"))
+
+
+def lora_trainable_shapes(geo, r, with_newline=False):
+    """Trainables of a LoRA run (train/train.py:1515-1532 + :1613-1665): the projector (non-LoRA trainable) and, for every
+    LM linear except lm_head (find_all_linear_names :242-255), lora_A [r, in] and lora_B [out, r] -- forward order."""
+    v, l = geo["vision"], geo["lm"]
+    s = OrderedDict()
+    s["model.mm_projector.0.weight"] = (l["d"], v["d"])
+    s["model.mm_projector.0.bias"] = (l["d"],)
+    s["model.mm_projector.2.weight"] = (l["d"], l["d"])
+    s["model.mm_projector.2.bias"] = (l["d"],)
+    if with_newline:
+        s["model.image_newline"] = (l["d"],)
+    for i in range(l["layers"]):
+        for t, o, k in LORA_TARGETS:
+            s[f"model.layers.{i}.{t}.lora_A.weight"] = (r, l[k])
+            s[f"model.layers.{i}.{t}.lora_B.weight"] = (l[o], r)
+    return s
+
+
 def vision_param_shapes(geo):
     v = geo["vision"]
     npos = (v["image"] // v["patch"]) ** 2 + 1

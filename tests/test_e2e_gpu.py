@@ -194,3 +194,56 @@ def test_reference_api_surface_and_trainer(golden_dir, tmp_path):
                              group_by_modality_length=True, warmup_ratio=0.0)
     state = LLaVATrainer(model=model, tokenizer=tok, args=args, **module).train()
     assert state["global_step"] == 3 and all(np.isfinite(r["loss"]) for r in state["log_history"])
+
+
+def test_toy_lora(golden_dir):
+    """BASELINE config 5 path at toy size: frozen LM + LoRA adapters (r=8, alpha=16, dropout 0) + trainable projector,
+    against the oracle's LoRA restatement (parity unpinned upstream: peft absent, no reference fixtures)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import llava_oracle as O
+    from radvlm_amd import portable_rng as prng
+    from radvlm_amd.engine import LlavaEngine
+    geo = GEOMETRIES["toy"]
+    g, meta, images = _golden(golden_dir, "toy_e2e")
+    eng = LlavaEngine(geo, device="cuda:0", init="portable", seed=0, lora=dict(r=8, alpha=16, dropout=0.0))
+    L = {}
+    for n in eng.lm.names():
+        if ".lora_" in n:
+            w = torch.from_numpy(prng.normal(3, prng.name_tag(n), eng.lm.shapes[n], 0.05))
+            eng.lm.view(n).copy_(w.to(torch.bfloat16))
+            L[n] = w.to(torch.bfloat16).float().requires_grad_(True)
+    loss = eng.forward(g["input_ids"], g["attention_mask"], g["labels"], images, want_logits=True)
+    logits = eng.last_logits.cpu()
+    eng.backward()
+    torch.cuda.synchronize()
+    P = O.make_params(geo, seed=0)
+    for k in P:
+        P[k] = P[k].to(torch.bfloat16).float()
+    for k in ("model.mm_projector.0.weight", "model.mm_projector.0.bias", "model.mm_projector.2.weight", "model.mm_projector.2.bias"):
+        P[k].requires_grad_(True)
+    Pe = O.apply_lora(P, L, geo, 16 / 8)
+    rl, rlog, _ = O.llava_forward(Pe, geo, torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"]),
+                                  torch.from_numpy(g["labels"]), images)
+    rl.backward()
+    assert abs(float(loss) - float(rl)) < 5e-3
+    m = torch.from_numpy(g["splice_attention_mask"])
+    assert float((logits[m] - rlog.detach()[m]).abs().max() / rlog.detach()[m].abs().max()) < 3e-2
+    for n, ref in list(L.items()) + [(k, P[k]) for k in P if P[k].grad is not None]:
+        got = eng.G(n).float().cpu()
+        rel = float((got - ref.grad).norm() / ref.grad.norm().clamp_min(1e-8))
+        assert rel < 6e-2, (n, rel)
+    # only adapters + projector are trainable: the flat gradient buffer is ~2 % of the model
+    assert eng.grads.numel() < 0.2 * eng.base.numel
+    # dropout > 0 runs and regenerates its masks in backward
+    eng2 = LlavaEngine(geo, device="cuda:0", init="portable", seed=0, lora=dict(r=8, alpha=16, dropout=0.05))
+    for n in eng2.lm.names():
+        if ".lora_B" in n:
+            eng2.lm.view(n).normal_(0, 0.05)
+    l2 = eng2.forward(g["input_ids"], g["attention_mask"], g["labels"], images)
+    eng2.backward()
+    eng2.optimizer_step(lr=1e-3, max_grad_norm=1.0)
+    torch.cuda.synchronize()
+    assert np.isfinite(float(l2)) and bool(torch.isfinite(eng2.lm.flat.float()).all())
+    ad, oth = eng2.lora_state_dict()
+    assert "base_model.model.model.layers.0.self_attn.q_proj.lora_A.default.weight" in ad and "model.mm_projector.0.weight" in oth

@@ -322,3 +322,18 @@ def test_gemm_transposed_operands(ops, M, N, K, ta, tb):
     if float(exact.abs().max()) < 2 ** 24:
         got = ops.gemm(gai, gbi, ta=ta, tb=tb, out_dtype=torch.float32)
         assert torch.equal(got.cpu().double(), exact)
+
+
+def test_dropout_and_alpha(ops):
+    x = rnd(60, (512, 256)).cuda()
+    y = ops.dropout(x, 0.25, 1234)
+    y2 = ops.dropout(x, 0.25, 1234)
+    assert torch.equal(y, y2)                                 # same (p, seed) regenerates the mask (used by backward)
+    keep = (y != 0) | (x == 0)
+    frac = float(keep.float().mean())
+    assert abs(frac - 0.75) < 0.01
+    assert relerr(y[keep], x[keep].float() / 0.75) < TOL
+    assert not torch.equal(ops.dropout(x, 0.25, 1235), y)
+    a, b = rnd(61, (96, 64)).cuda(), rnd(62, (80, 64)).cuda()
+    out = ops.gemm(a, b, alpha=0.25, out_dtype=torch.float32)
+    assert relerr(out, 0.25 * (a.float().cpu() @ b.float().cpu().t())) < 1e-5
