@@ -223,11 +223,13 @@ DEVINL void frag_issue(Frag& f, const char* tile, int fbase, int kk, int lane) {
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.t0) : "v"(o0) : "memory");
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.t1) : "v"(o1) : "memory");
 }
-template <bool T>
+// LEFT = number of younger LDS operations that may stay in flight (LDS ops retire in order; compiler-issued reads in
+// between only make the wait stricter, never weaker).
+template <bool T, int LEFT = 0>
 DEVINL void frag_wait4(Frag& a, Frag& b, Frag& c, Frag& d) {
     if (!T) return;
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a.t0), "+v"(a.t1), "+v"(b.t0), "+v"(b.t1), "+v"(c.t0), "+v"(c.t1), "+v"(d.t0), "+v"(d.t1) :: "memory");
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(a.t0), "+v"(a.t1), "+v"(b.t0), "+v"(b.t1), "+v"(c.t0), "+v"(c.t1), "+v"(d.t0), "+v"(d.t1) : "i"(LEFT) : "memory");
 }
 template <bool T>
 DEVINL bf16x8 frag_get(const Frag& f) {
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
         Frag fa[4][2], fb[2][2][2];
         bf16x8 a[4][2], b[2][2][2];
 
-        // ---- phase 1
+        // ---- phase 1: read A(mh0), B(nh0) and, ahead of time, B(nh1)
         if (t + 2 < nt) stageA(t + 2, aslot2, 0);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -289,9 +291,14 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) frag_issue<TA>(fa[i][kk], At, i * 16, kk, lane);
         }
-        frag_wait4<TB>(fb[0][0][0], fb[0][1][0], fb[0][0][1], fb[0][1][1]);
-        frag_wait4<TA>(fa[0][0], fa[1][0], fa[2][0], fa[3][0]);
-        frag_wait4<TA>(fa[0][1], fa[1][1], fa[2][1], fa[3][1]);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) frag_issue<TB>(fb[1][j][kk], Bt, brow0 + 32 + j * 16, kk, lane);
+        constexpr int B1_OPS = TB ? 8 : 4;   // the B(nh1) prefetch stays in flight behind phase 1's MFMAs
+        frag_wait4<TB, B1_OPS>(fb[0][0][0], fb[0][1][0], fb[0][0][1], fb[0][1][1]);
+        frag_wait4<TA, B1_OPS>(fa[0][0], fa[1][0], fa[2][0], fa[3][0]);
+        frag_wait4<TA, B1_OPS>(fa[0][1], fa[1][1], fa[2][1], fa[3][1]);
         if (TA || TB) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -309,12 +316,8 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
                 for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(b[0][j][kk], a[i][kk], acc[i][j]);
         __builtin_amdgcn_s_setprio(0);
 
-        // ---- phase 2
+        // ---- phase 2: B(nh1) has landed behind phase 1's MFMAs; A(mh1) is read k-step by k-step behind this phase's MFMAs
         if (t + 2 < nt) stageA(t + 2, aslot2, 1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) frag_issue<TB>(fb[1][j][kk], Bt, brow0 + 32 + j * 16, kk, lane);
         BAR_LGKM();   // every wave's B reads of tile t are complete -> the B slot of tile t may be restaged
         frag_wait4<TB>(fb[1][0][0], fb[1][1][0], fb[1][0][1], fb[1][1][1]);
         if (TB) __builtin_amdgcn_sched_barrier(0);
@@ -322,36 +325,35 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int j = 0; j < 2; ++j) b[1][j][kk] = frag_get<TB>(fb[1][j][kk]);
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < 2; ++kk) {
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma16(b[1][j][kk], a[i][kk], acc[i][2 + j]);
-        __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
+            // a[.][kk] is dead now: fetch A(mh1) for this k-step while the other k-step's MFMAs run
+#pragma unroll
+            for (int i = 0; i < 4; ++i) frag_issue<TA>(fa[i][kk], At, 64 + i * 16, kk, lane);
+        }
 
         // ---- phase 3
         if (t + 2 < nt) stageB(t + 2, 0);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) frag_issue<TA>(fa[i][kk], At, 64 + i * 16, kk, lane);
-        frag_wait4<TA>(fa[0][0], fa[1][0], fa[2][0], fa[3][0]);
-        frag_wait4<TA>(fa[0][1], fa[1][1], fa[2][1], fa[3][1]);
-        if (TA) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < 2; ++kk) {
+            if (kk == 0) frag_wait4<TA, 8>(fa[0][0], fa[1][0], fa[2][0], fa[3][0]);   // the k-step-1 reads stay in flight
+            else frag_wait4<TA, 0>(fa[0][1], fa[1][1], fa[2][1], fa[3][1]);
+            if (TA) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[i][kk] = frag_get<TA>(fa[i][kk]);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = mfma16(b[1][j][kk], a[i][kk], acc[4 + i][2 + j]);
-        __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
+        }
 
         // ---- phase 4
         if (t + 2 < nt) stageB(t + 2, 1);
