@@ -49,9 +49,13 @@ int rv_gemm_select_kernel(int which);
 
 /* Batched strided transpose of bf16 matrices: out[bz][c][r] = in[bz][r][c], r < R, c < C; columns r in [R, R_pad)
  * of every output row are written as zero.  bz = b0 * nb1 + b1; offsets in elements.
- * Used for: W^T copies (dgrad), X^T / dY^T (wgrad), and the [b,h,hd,S_pad] head-transposed attention operands. */
+ * Used for the [b,h,hd,S_pad] head-transposed attention operands (perm32 = 1: within every aligned group of 32
+ * output columns, column 8g + 4h + j holds input row 16h + 4g + j -- the order in which an MFMA accumulator tile
+ * presents the sequence axis as the next MFMA's contraction index, so each lane's 8 operands are one 16-byte read;
+ * requires R_pad % 64 == 0). */
 int rv_transpose_bf16(const void* in, int64_t in_ld, int64_t in_bs0, int64_t in_bs1, void* out, int64_t out_ld,
-                      int64_t out_bs0, int64_t out_bs1, int R, int C, int R_pad, int nb0, int nb1, void* stream);
+                      int64_t out_bs0, int64_t out_bs1, int R, int C, int R_pad, int nb0, int nb1, int perm32,
+                      void* stream);
 
 /* ---- normalisation ------------------------------------------------------------------------------------------
  * LlamaRMSNorm.forward (modeling_llama.py:82-87): y = w * bf16(x * rsqrt(mean(x^2) + eps)), fp32 internal.

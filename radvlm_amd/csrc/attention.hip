@@ -7,7 +7,7 @@
 //
 // MFMA: v_mfma_f32_16x16x32_bf16 only. Every operand is read contraction-contiguous from an XOR-swizzled LDS
 // tile (ds_read_b128 / ds_read_b64); operands whose contraction index is the sequence axis come from
-// pre-transposed global copies [b,h,hd,S_pad] (rv_transpose_bf16), so no LDS transposes are needed.
+// pre-transposed global copies [b,h,hd,S_pad] (rv_transpose_bf16, perm32 order), so no LDS transposes are needed.
 // The score tile produced by one MFMA chain is reused as the next chain's B operand straight from the
 // accumulator registers (contraction order kappa(g,j) = 16*(2p + (j>>2)) + 4g + (j&3), matched by the A-side reads).
 //
@@ -32,13 +32,14 @@ struct AttnParams {
 template <int ROW_BYTES> DEVINL int swz(int r) { return ROW_BYTES == 128 ? ((r >> 1) & 7) : (r & 15); }
 
 // Stage NROWS rows of ROW_BYTES each into an LDS tile; rows >= valid_rows come from the zero page.
-template <int ROW_BYTES, int NROWS>
+template <int ROW_BYTES, int NROWS, int NW = 4>
 DEVINL void stage_rows(const bf16* src, long row_stride, int valid_rows, const bf16* zeros, char* lds, int wid, int lane) {
     constexpr int CPR = ROW_BYTES / 16;
     constexpr int NI = NROWS * CPR / 64;  // wave-instructions for the tile
+    static_assert(NI % NW == 0, "tile must split evenly over the block's waves");
 #pragma unroll
-    for (int i = 0; i < NI / 4; ++i) {
-        const int it = i * 4 + wid;
+    for (int i = 0; i < NI / NW; ++i) {
+        const int it = i * NW + wid;
         const int c = it * 64 + lane;
         const int r = c / CPR, p = c % CPR;
         const int lc = p ^ swz<ROW_BYTES>(r);
@@ -50,13 +51,10 @@ DEVINL void stage_rows(const bf16* src, long row_stride, int valid_rows, const b
 template <int ROW_BYTES> DEVINL bf16x8 rd128(const char* tile, int row, int chunk) {
     return *(const bf16x8*)(tile + row * ROW_BYTES + ((chunk ^ swz<ROW_BYTES>(row)) << 4));
 }
-// A-operand for a contraction over the tile's 64 columns in kappa order: pair p in {0,1}, lane group g.
-DEVINL bf16x8 rdT(const char* tile, int row, int p, int g) {
-    const int s = swz<128>(row);
-    const bf16x4 lo = *(const bf16x4*)(tile + row * 128 + (((4 * p + (g >> 1)) ^ s) << 4) + ((g & 1) << 3));
-    const bf16x4 hi = *(const bf16x4*)(tile + row * 128 + (((4 * p + 2 + (g >> 1)) ^ s) << 4) + ((g & 1) << 3));
-    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-}
+// A-operand for a contraction over the tile's 64 (sequence) columns: pair p in {0,1} = 32 columns, lane group g.
+// The transposed global copies are written in MFMA contraction order (rv_transpose_bf16 perm32), so the 8 operands
+// kappa(g, 0..7) of a lane are the 16 contiguous bytes of chunk 4p + g: one conflict-free ds_read_b128.
+DEVINL bf16x8 rdT(const char* tile, int row, int p, int g) { return rd128<128>(tile, row, 4 * p + g); }
 DEVINL bf16x8 pack8(f32x4 a, f32x4 b) {
     return bf16x8{f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
 }
@@ -67,7 +65,7 @@ constexpr float LN2 = 0.6931471805599453f;
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams P) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
     constexpr int KS = HD / 32, DB = HD / 16, KROW = HD * 2;
     constexpr int KT_BYTES = 64 * KROW, VT_BYTES = HD * 128, STAGE = KT_BYTES + VT_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -212,14 +210,14 @@ __global__ void attn_delta_kernel(AttnParams P, int HD) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
-template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P) {
+template <int HD, bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dq_kernel(AttnParams P) {
     constexpr int KS = HD / 32, DB = HD / 16, KROW = HD * 2;
     constexpr int NAT_BYTES = 64 * KROW, T_BYTES = HD * 128, STAGE = 2 * NAT_BYTES + T_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wid = wave_id(), lane = lane_id(), g = lane >> 4, c = lane & 15;
     const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int S = P.S, q0 = qblk * 128 + wid * 32;
+    const int S = P.S, q0 = qblk * (32 * NW) + wid * 32;
     const int len = P.lens ? P.lens[b] : S;
     const float sl2 = P.scale * LOG2E;
 
@@ -235,7 +233,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P) {
         lse2[qs] = P.lse[(long)(b * P.H + h) * P.S_pad + row] * LOG2E;
         dl[qs] = P.delta[(long)(b * P.H + h) * P.S_pad + row];
     }
-    const int kv_end = CAUSAL ? min(len, qblk * 128 + 128) : len;
+    const int kv_end = CAUSAL ? min(len, (qblk + 1) * (32 * NW)) : len;
     const int ntiles = (kv_end + 63) >> 6;
     const bf16* kbase = P.k + (long)b * S * P.ld_k + h * HD;
     const bf16* vbase = P.v + (long)b * S * P.ld_v + h * HD;
@@ -247,9 +245,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P) {
 #pragma unroll
         for (int db = 0; db < DB; ++db) dq[qs][db] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    stage_rows<KROW, 64>(kbase, P.ld_k, S, P.zeros, smem, wid, lane);
-    stage_rows<KROW, 64>(vbase, P.ld_v, S, P.zeros, smem + NAT_BYTES, wid, lane);
-    stage_rows<128, HD>(ktbase, P.S_pad, HD, P.zeros, smem + 2 * NAT_BYTES, wid, lane);
+    stage_rows<KROW, 64, NW>(kbase, P.ld_k, S, P.zeros, smem, wid, lane);
+    stage_rows<KROW, 64, NW>(vbase, P.ld_v, S, P.zeros, smem + NAT_BYTES, wid, lane);
+    stage_rows<128, HD, NW>(ktbase, P.S_pad, HD, P.zeros, smem + 2 * NAT_BYTES, wid, lane);
 
     for (int t = 0; t < ntiles; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -260,9 +258,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P) {
         if (t + 1 < ntiles) {
             char* nx = smem + ((t + 1) & 1) * STAGE;
             const int kv1 = (t + 1) * 64;
-            stage_rows<KROW, 64>(kbase + (long)kv1 * P.ld_k, P.ld_k, S - kv1, P.zeros, nx, wid, lane);
-            stage_rows<KROW, 64>(vbase + (long)kv1 * P.ld_v, P.ld_v, S - kv1, P.zeros, nx + NAT_BYTES, wid, lane);
-            stage_rows<128, HD>(ktbase + kv1, P.S_pad, HD, P.zeros, nx + 2 * NAT_BYTES, wid, lane);
+            stage_rows<KROW, 64, NW>(kbase + (long)kv1 * P.ld_k, P.ld_k, S - kv1, P.zeros, nx, wid, lane);
+            stage_rows<KROW, 64, NW>(vbase + (long)kv1 * P.ld_v, P.ld_v, S - kv1, P.zeros, nx + NAT_BYTES, wid, lane);
+            stage_rows<128, HD, NW>(ktbase + kv1, P.S_pad, HD, P.zeros, nx + 2 * NAT_BYTES, wid, lane);
         }
         const int kv0 = t * 64;
         if (CAUSAL && kv0 > q0 + 31) continue;
@@ -324,20 +322,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams P) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P) {
+template <int HD, bool CAUSAL, int NW, int NKB>
+__global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dkv_kernel(AttnParams P) {
     constexpr int KS = HD / 32, DB = HD / 16, KROW = HD * 2;
-    constexpr int NAT_BYTES = 64 * KROW, T_BYTES = HD * 128, STAGE = 2 * NAT_BYTES + 2 * T_BYTES;
+    constexpr int NAT_BYTES = 64 * KROW, T_BYTES = HD * 128, STAGE = 2 * NAT_BYTES + 2 * T_BYTES + 1024;  // + lse|delta
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wid = wave_id(), lane = lane_id(), g = lane >> 4, c = lane & 15;
     const int kblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int S = P.S, k0 = kblk * 128 + wid * 32;
+    constexpr int KPB = NW * NKB * 16;   // keys per block
+    const int S = P.S, k0 = kblk * KPB + wid * (16 * NKB);
     const int len = P.lens ? P.lens[b] : S;
     const float sl2 = P.scale * LOG2E;
 
-    bf16x8 kf[2][KS], vf[2][KS];
+    bf16x8 kf[NKB][KS], vf[NKB][KS];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < NKB; ++kb) {
         const int row = min(k0 + kb * 16 + c, S - 1);
         const bf16* kp = P.k + (long)(b * S + row) * P.ld_k + h * HD + g * 8;
         const bf16* vp = P.v + (long)(b * S + row) * P.ld_v + h * HD + g * 8;
@@ -345,7 +344,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P) {
         for (int ks = 0; ks < KS; ++ks) { kf[kb][ks] = *(const bf16x8*)(kp + ks * 32); vf[kb][ks] = *(const bf16x8*)(vp + ks * 32); }
     }
     const int q_end = len;  // query rows >= len carry zero dO
-    const int t0 = CAUSAL ? (kblk * 128) >> 6 : 0;
+    const int t0 = CAUSAL ? (kblk * KPB) >> 6 : 0;
     const int t1 = (q_end + 63) >> 6;
     const bf16* qbase = P.q + (long)b * S * P.ld_q + h * HD;
     const bf16* dobase = P.dout + (long)b * S * P.ld_do + h * HD;
@@ -354,18 +353,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P) {
     const float* lsebase = P.lse + (long)(b * P.H + h) * P.S_pad;
     const float* dlbase = P.delta + (long)(b * P.H + h) * P.S_pad;
 
-    f32x4 dv[DB][2], dk[DB][2];
+    f32x4 dv[DB][NKB], dk[DB][NKB];
 #pragma unroll
     for (int db = 0; db < DB; ++db)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) { dv[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int kb = 0; kb < NKB; ++kb) { dv[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     auto stage = [&](int t, char* dst) {
         const int qt0 = t * 64;
-        stage_rows<KROW, 64>(qbase + (long)qt0 * P.ld_q, P.ld_q, S - qt0, P.zeros, dst, wid, lane);
-        stage_rows<KROW, 64>(dobase + (long)qt0 * P.ld_do, P.ld_do, S - qt0, P.zeros, dst + NAT_BYTES, wid, lane);
-        stage_rows<128, HD>(qtbase + qt0, P.S_pad, HD, P.zeros, dst + 2 * NAT_BYTES, wid, lane);
-        stage_rows<128, HD>(dotbase + qt0, P.S_pad, HD, P.zeros, dst + 2 * NAT_BYTES + T_BYTES, wid, lane);
+        stage_rows<KROW, 64, NW>(qbase + (long)qt0 * P.ld_q, P.ld_q, S - qt0, P.zeros, dst, wid, lane);
+        stage_rows<KROW, 64, NW>(dobase + (long)qt0 * P.ld_do, P.ld_do, S - qt0, P.zeros, dst + NAT_BYTES, wid, lane);
+        stage_rows<128, HD, NW>(qtbase + qt0, P.S_pad, HD, P.zeros, dst + 2 * NAT_BYTES, wid, lane);
+        stage_rows<128, HD, NW>(dotbase + qt0, P.S_pad, HD, P.zeros, dst + 2 * NAT_BYTES + T_BYTES, wid, lane);
+        // lse / delta of the tile's 64 query rows ride the same LDS-DMA stream (a plain global load here would make
+        // hipcc drain vmcnt(0) -- i.e. the whole prefetched tile -- before every use)
+        if (wid == 0) {
+            const float* g = lane < 16 ? lsebase + qt0 + lane * 4 : (lane < 32 ? dlbase + qt0 + (lane - 16) * 4 : (const float*)P.zeros);
+            glds16(g, dst + 2 * NAT_BYTES + 2 * T_BYTES);
+        }
     };
     if (t0 < t1) stage(t0, smem);
 
@@ -376,17 +381,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P) {
         const char* dOt = Qt + NAT_BYTES;
         const char* QTt = Qt + 2 * NAT_BYTES;
         const char* dOTt = QTt + T_BYTES;
+        const char* LSt = dOTt + T_BYTES;   // [64 lse | 64 delta] fp32
         if (t + 1 < t1) stage(t + 1, smem + ((t + 1 - t0) & 1) * STAGE);
         const int qt0 = t * 64;
         if (CAUSAL && qt0 + 63 < k0) continue;  // every query of this tile precedes this wave's keys
 
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp) {
-            f32x4 s[2][2], dp[2][2];
+            f32x4 s[2][NKB], dp[2][NKB];
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) { s[qq][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qq][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                for (int kb = 0; kb < NKB; ++kb) { s[qq][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qq][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
                 const int qb = 2 * qp + qq;
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P) {
                     const bf16x8 qa = rd128<KROW>(Qt, qb * 16 + c, ks * 4 + g);
                     const bf16x8 da = rd128<KROW>(dOt, qb * 16 + c, ks * 4 + g);
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb) {
+                    for (int kb = 0; kb < NKB; ++kb) {
                         s[qq][kb] = mfma16(qa, kf[kb][ks], s[qq][kb]);
                         dp[qq][kb] = mfma16(da, vf[kb][ks], dp[qq][kb]);
                     }
@@ -405,10 +411,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P) {
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
                 const int qrow = qt0 + (2 * qp + qq) * 16 + 4 * g;
-                const f32x4 ls = *(const f32x4*)(lsebase + qrow);
-                const f32x4 dl = *(const f32x4*)(dlbase + qrow);
+                const f32x4 ls = *(const f32x4*)(LSt + (qrow - qt0) * 4);
+                const f32x4 dl = *(const f32x4*)(LSt + 256 + (qrow - qt0) * 4);
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
+                for (int kb = 0; kb < NKB; ++kb) {
                     const int kidx = k0 + kb * 16 + c;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -420,15 +426,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P) {
                     }
                 }
             }
-            bf16x8 pf[2], dsf[2];
+            bf16x8 pf[NKB], dsf[NKB];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) { pf[kb] = pack8(s[0][kb], s[1][kb]); dsf[kb] = pack8(dp[0][kb], dp[1][kb]); }
+            for (int kb = 0; kb < NKB; ++kb) { pf[kb] = pack8(s[0][kb], s[1][kb]); dsf[kb] = pack8(dp[0][kb], dp[1][kb]); }
 #pragma unroll
             for (int db = 0; db < DB; ++db) {
                 const bf16x8 dota = rdT(dOTt, db * 16 + c, qp, g);
                 const bf16x8 qta = rdT(QTt, db * 16 + c, qp, g);
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb) {
+                for (int kb = 0; kb < NKB; ++kb) {
                     dv[db][kb] = mfma16(dota, pf[kb], dv[db][kb]);
                     dk[db][kb] = mfma16(qta, dsf[kb], dk[db][kb]);
                 }
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams P) {
     }
     // lane holds dV^T[d = 16db + 4g + r][key = k0 + 16kb + c]
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int kb = 0; kb < NKB; ++kb) {
         const int kidx = k0 + kb * 16 + c;
         if (kidx >= S) continue;
         bf16* vp = P.dv + (long)(b * S + kidx) * P.ld_dv + h * HD + 4 * g;
@@ -502,15 +508,16 @@ extern "C" int rv_attn_bwd(const void* q, int64_t ld_q, const void* k, int64_t l
     hipStream_t st = (hipStream_t)stream;
     const int nw = B * S * H;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((nw * 64 + 255) / 256), dim3(256), 0, st, P, HD);
-    dim3 grid((S + 127) / 128, H, B);
+    // 8 waves per block (2 per SIMD): dQ pass = 256 query rows per block, dK/dV pass = 128 keys per block (16 per wave)
+    dim3 grid_dq((S + 255) / 256, H, B), grid_dkv((S + 127) / 128, H, B);
     const int smem_dq = 2 * (2 * 64 * HD * 2 + HD * 128);
-    const int smem_dkv = 2 * (2 * 64 * HD * 2 + 2 * HD * 128);
+    const int smem_dkv = 2 * (2 * 64 * HD * 2 + 2 * HD * 128 + 1024);
 #define LAUNCH_BWD(HD_, C_)                                                                                    \
     do {                                                                                                       \
-        set_smem(attn_bwd_dq_kernel<HD_, C_>, smem_dq);                                                        \
-        set_smem(attn_bwd_dkv_kernel<HD_, C_>, smem_dkv);                                                      \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_, C_>), grid, dim3(256), smem_dq, st, P);                    \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD_, C_>), grid, dim3(256), smem_dkv, st, P);                  \
+        set_smem(attn_bwd_dq_kernel<HD_, C_, 8>, smem_dq);                                                     \
+        set_smem(attn_bwd_dkv_kernel<HD_, C_, 8, 1>, smem_dkv);                                                \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_, C_, 8>), grid_dq, dim3(512), smem_dq, st, P);              \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD_, C_, 8, 1>), grid_dkv, dim3(512), smem_dkv, st, P);        \
     } while (0)
     if (HD == 128) { if (causal) LAUNCH_BWD(128, true); else LAUNCH_BWD(128, false); }
     else { if (causal) LAUNCH_BWD(64, true); else LAUNCH_BWD(64, false); }

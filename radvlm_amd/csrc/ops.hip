@@ -240,13 +240,23 @@ __global__ void quick_gelu_bwd_kernel(const bf16* dy, const bf16* x, bf16* dx, l
 }
 
 // ------------------------------------------------------------------------------------------------ column sums
-__global__ void colsum_f32_kernel(const float* in, int rows, int cols, bf16* out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+// 32 columns x 8 row-lanes per 256-thread block: each lane strides the rows by 8, then one LDS hop combines them
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* in, int rows, int cols, bf16* out, int accumulate) {
+    __shared__ float red[8][33];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += in[(long)r * cols + c];
-    if (accumulate) s += bf2f(out[c]);
-    out[c] = f2bf(s);
+    if (c < cols)
+        for (int r = rl; r < rows; r += 8) s += in[(long)r * cols + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t += red[i][cl];
+        if (accumulate) t += bf2f(out[c]);
+        out[c] = f2bf(t);
+    }
 }
 
 __global__ __launch_bounds__(TPB) void colsum_partial_kernel(const bf16* x, long ld, int rows, int cols, float* partial) {
@@ -502,7 +512,7 @@ __global__ void clip_embed_kernel(const bf16* patch_out, const bf16* cls, const 
 // ------------------------------------------------------------------------------------------------ transpose
 // 64x64 tiles through LDS; out row c holds in[.., c] for r in [0, R_pad) (zeros beyond R).
 __global__ __launch_bounds__(TPB) void transpose_kernel(const bf16* in, long in_ld, long in_bs0, long in_bs1, bf16* out, long out_ld,
-                                                        long out_bs0, long out_bs1, int R, int C, int R_pad, int nb1) {
+                                                        long out_bs0, long out_bs1, int R, int C, int R_pad, int nb1, int perm32) {
     __shared__ bf16 tile[64][72];
     const int bz = blockIdx.z, b0 = bz / nb1, b1 = bz % nb1;
     const bf16* src = in + b0 * in_bs0 + b1 * in_bs1;
@@ -528,8 +538,15 @@ __global__ __launch_bounds__(TPB) void transpose_kernel(const bf16* in, long in_
         const int c = ch >> 3, rr = (ch & 7) * 8;
         if (c0 + c < C && r0 + rr < R_pad) {
             bf16x8 v;
+            if (perm32) {
+                // MFMA contraction order within each group of 32: output position 8g + 4h + j holds r = 16h + 4g + j
+                const int q = ch & 7, base = (q >> 2) * 32 + (q & 3) * 4;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = tile[rr + i][c];
+                for (int i = 0; i < 8; ++i) v[i] = tile[base + (i >> 2) * 16 + (i & 3)][c];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] = tile[rr + i][c];
+            }
             *(bf16x8*)(dst + (long)(c0 + c) * out_ld + r0 + rr) = v;
         }
     }
@@ -664,7 +681,7 @@ extern "C" int rv_quick_gelu_bwd(const void* dy, const void* x, void* dx, int64_
 }
 extern "C" int rv_colsum_f32(const float* in, int rows, int cols, void* out, int accumulate, void* stream) {
     if (!in || !out || rows <= 0 || cols <= 0) return RV_ERR_ARG;
-    hipLaunchKernelGGL(colsum_f32_kernel, dim3(nblocks(cols, 256)), dim3(256), 0, ST, in, rows, cols, (bf16*)out, accumulate);
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3(nblocks(cols, 32)), dim3(256), 0, ST, in, rows, cols, (bf16*)out, accumulate);
     return rv_check_launch();
 }
 extern "C" int rv_colsum_partial_bf16(const void* x, int64_t ld, int rows, int cols, float* partial, int nblk, void* stream) {
@@ -740,13 +757,15 @@ extern "C" int rv_clip_embed(const void* patch_out, const void* cls, const void*
     return rv_check_launch();
 }
 extern "C" int rv_transpose_bf16(const void* in, int64_t in_ld, int64_t in_bs0, int64_t in_bs1, void* out, int64_t out_ld,
-                                 int64_t out_bs0, int64_t out_bs1, int R, int C, int R_pad, int nb0, int nb1, void* stream) {
+                                 int64_t out_bs0, int64_t out_bs1, int R, int C, int R_pad, int nb0, int nb1, int perm32,
+                                 void* stream) {
     if (!in || !out || R <= 0 || C <= 0 || R_pad < R || (R_pad & 7) || nb0 <= 0 || nb1 <= 0) return RV_ERR_ARG;
     if ((in_ld & 7) || (out_ld & 7) || (in_bs0 & 7) || (in_bs1 & 7) || (out_bs0 & 7) || (out_bs1 & 7)) return RV_ERR_ARG;
     if ((((uintptr_t)in) | ((uintptr_t)out)) & 15) return RV_ERR_ARG;
+    if (perm32 && (R_pad & 63)) return RV_ERR_ARG;
     dim3 grid((R_pad + 63) / 64, (C + 63) / 64, nb0 * nb1);
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(TPB), 0, ST, (const bf16*)in, (long)in_ld, (long)in_bs0, (long)in_bs1, (bf16*)out,
-                       (long)out_ld, (long)out_bs0, (long)out_bs1, R, C, R_pad, nb1);
+                       (long)out_ld, (long)out_bs0, (long)out_bs1, R, C, R_pad, nb1, perm32);
     return rv_check_launch();
 }
 extern "C" int rv_adamw(void* p, float* master, const void* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,

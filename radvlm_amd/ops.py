@@ -73,18 +73,19 @@ def transpose(x, r_pad=None, out=None):
     if out is None:
         out = torch.empty(C, r_pad, dtype=BF16, device=x.device)
     assert out.shape == (C, r_pad) and out.stride(1) == 1 and x.stride(1) == 1
-    lib.call("rv_transpose_bf16", x, x.stride(0), 0, 0, out, out.stride(0), 0, 0, R, C, r_pad, 1, 1)
+    lib.call("rv_transpose_bf16", x, x.stride(0), 0, 0, out, out.stride(0), 0, 0, R, C, r_pad, 1, 1, 0)
     return out
 
 
-def transpose_heads(x, B, S, H, hd, s_pad, out=None):
-    """x: token-major view [(b*S+s), H*hd] (row stride ld) -> [B,H,hd,s_pad] (zero padded along s)."""
+def transpose_heads(x, B, S, H, hd, s_pad, out=None, perm32=True):
+    """x: token-major view [(b*S+s), H*hd] (row stride ld) -> [B,H,hd,s_pad] (zero padded along s).
+    perm32 (what the attention kernels expect): the sequence axis is stored in MFMA contraction order per group of 32."""
     _chk(x)
     assert x.shape == (B * S, H * hd) and x.stride(1) == 1
     if out is None:
         out = torch.empty(B, H, hd, s_pad, dtype=BF16, device=x.device)
     ld = x.stride(0)
-    lib.call("rv_transpose_bf16", x, ld, S * ld, hd, out, s_pad, H * hd * s_pad, hd * s_pad, S, hd, s_pad, B, H)
+    lib.call("rv_transpose_bf16", x, ld, S * ld, hd, out, s_pad, H * hd * s_pad, hd * s_pad, S, hd, s_pad, B, H, int(perm32))
     return out
 
 

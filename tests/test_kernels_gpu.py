@@ -84,10 +84,16 @@ def test_transpose(ops):
     B, S, H, hd = 2, 50, 3, 64
     qkv = rnd(8, (B * S, 3 * H * hd)).cuda()
     k = qkv[:, H * hd:2 * H * hd]
-    kt = ops.transpose_heads(k, B, S, H, hd, 64)
+    kt = ops.transpose_heads(k, B, S, H, hd, 64, perm32=False)
     ref = k.cpu().view(B, S, H, hd).permute(0, 2, 3, 1)
     assert torch.equal(kt[..., :S].cpu(), ref)
     assert float(kt[..., S:].float().abs().max()) == 0.0
+    # perm32: position 8g + 4h + j of every aligned group of 32 holds sequence index 16h + 4g + j
+    ktp = ops.transpose_heads(k, B, S, H, hd, 64, perm32=True).cpu()
+    full = torch.zeros(B, H, hd, 64, dtype=torch.bfloat16)
+    full[..., :S] = ref
+    src = torch.tensor([(pos // 32) * 32 + 16 * ((pos % 8) // 4) + 4 * ((pos % 32) // 8) + pos % 4 for pos in range(64)])
+    assert torch.equal(ktp, full[..., src])
 
 
 def test_rmsnorm(ops):
