@@ -24,6 +24,16 @@ TF_PER_PAIR = {"llava15_7b": 28.75, "config1": 0.089, "toy": None}  # BASELINE.m
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
+def synthetic_batch_anyres(geo, b, seed):
+    """BASELINE config 4: 672x672 image, pinpoints [[336,672],[672,336],[672,672],[1008,336],[336,1008]], spatial_unpad ->
+    5 tiles, 2928 image tokens + 128 text tokens = S 3056."""
+    ids, mask, labels, _ = synthetic_batch(geo, b, seed)
+    g = torch.Generator().manual_seed(seed)
+    img = geo["vision"]["image"]
+    images = [torch.randn(5, 3, img, img, generator=g).to(torch.bfloat16) for _ in range(b)]
+    return ids, mask, labels, images, [(672, 672)] * b
+
+
 def synthetic_batch(geo, b, seed):
     """SURVEY.md section 8d inputs: ids uniform in [3, V), IMAGE_TOKEN_INDEX at 35, first 64 text positions ignored."""
     V = geo["lm"]["vocab"]
@@ -72,7 +82,7 @@ def cpu_baseline(geo, seconds_budget=25.0):
             fn()
         return (time.perf_counter() - t) / reps
 
-    t_dec = timeit(dec, 1)
+    t_dec = timeit(dec, 8)
     # ViT layer forward (frozen tower)
     dv, N = v["d"], (v["image"] // v["patch"]) ** 2 + 1
     vp = "model.vision_tower.vision_tower.vision_model."
@@ -80,7 +90,7 @@ def cpu_baseline(geo, seconds_budget=25.0):
     PV = {k: torch.randn(*shp, generator=g) * 0.02 for k, shp in O.param_shapes(geo1).items() if k.startswith(vp)}
     pix = torch.randn(1, 3, v["image"], v["image"], generator=g)
     with torch.no_grad():
-        t_vit = timeit(lambda: O.clip_vision_hidden(PV, geo1, pix, -2), 1)  # embeddings + 1 layer
+        t_vit = timeit(lambda: O.clip_vision_hidden(PV, geo1, pix, -2), 40)  # embeddings + 1 layer
     # head
     wh = (torch.randn(l["vocab"], d, generator=g) * 0.02).requires_grad_(True)
     hN = torch.randn(1, S, d, generator=g).requires_grad_(True)
@@ -89,7 +99,7 @@ def cpu_baseline(geo, seconds_budget=25.0):
     def head():
         O.causal_lm_loss(F.linear(hN, wh), lab).backward()
 
-    t_head = timeit(head, 1)
+    t_head = timeit(head, 4)
     step = l["layers"] * t_dec + (v["layers"] - 1) * t_vit + t_head
     return {"value": 1.0 / step, "unit": "pairs/s", "cores": cores, "kind": "port",
             "sample": f"oracle fp32, b=1: 1 decoder layer fwd+bwd ({t_dec:.2f}s) x{l['layers']} + 1 ViT layer fwd ({t_vit:.2f}s) "
@@ -141,6 +151,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="pairs per GPU per step (global batch 256 at 8 GPUs)")
     ap.add_argument("--geometry", default="llava15_7b")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="cxr", choices=["cxr", "anyres", "lora"],
+                    help="cxr = BASELINE configs 2/3 (headline); anyres = config 4 (S=3056); lora = config 5 (r=64 adapters)")
     ap.add_argument("--lr", type=float, default=2e-5)
     args = ap.parse_args()
 
@@ -158,9 +170,15 @@ def main():
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
         pg = torch.distributed.group.WORLD
     geo = GEOMETRIES[args.geometry]
-    eng = LlavaEngine(geo, device=f"cuda:{local}", init="fast", seed=0, process_group=pg)
+    kw = {}
+    if args.workload == "anyres":
+        kw = dict(merge_type="spatial_unpad", image_aspect_ratio="anyres",
+                  image_grid_pinpoints=[[336, 672], [672, 336], [672, 672], [1008, 336], [336, 1008]])
+    if args.workload == "lora":
+        kw = dict(lora=dict(r=64, alpha=16, dropout=0.05))
+    eng = LlavaEngine(geo, device=f"cuda:{local}", init="fast", seed=0, process_group=pg, **kw)
     eng.init_optimizer()
-    batch = synthetic_batch(geo, args.batch, seed=1234 + rank)
+    batch = (synthetic_batch_anyres if args.workload == "anyres" else synthetic_batch)(geo, args.batch, seed=1234 + rank)
 
     def step():
         loss = eng.forward(*batch)
@@ -197,7 +215,13 @@ def main():
     roofline = {"bound": "mfma", "kernel": "gemm_kernel_256 (all operand forms; 128x128 kernel for small shapes)", "achieved": gflops / (gms * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "traffic": None, "launches_per_step": nlaunch, "gemm_ms_per_step": gms}
     roofline["frac"] = roofline["achieved"] / roofline["peak"]
-    tf_pair = TF_PER_PAIR.get(args.geometry)
+    try:  # HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE)
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm_hbm_traffic.json")) as f:
+            roofline["traffic"] = json.load(f)["gemm_kernel_256"]["hbm_bytes_per_launch"] if args.workload == "cxr" and args.batch == 32 else None
+        roofline["traffic_source"] = "profiles/r01_pmc_gemm_hbm_traffic.json (separate --pmc passes of this command)"
+    except OSError:
+        pass
+    tf_pair = TF_PER_PAIR.get(args.geometry) if args.workload == "cxr" else None
     if tf_pair:
         roofline["step_algorithmic_tflops"] = tf_pair * args.batch / (ms_per_step * 1e-3)
         roofline["step_frac_of_mfma_peak"] = roofline["step_algorithmic_tflops"] / PEAK_BF16_TFLOPS
@@ -206,8 +230,10 @@ def main():
             "metric": "train image-instruction pairs/sec, LLaVA-1.5-7B 336px", "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.geometry} full fine-tune step (ViT frozen): fwd+bwd+AdamW, S=704, "
-                                   f"{args.batch} pairs/GPU/step", "global_batch": args.batch * world, "seq_len": 704,
+            "config": {"workload": f"{args.geometry} {'LoRA r=64' if args.workload == 'lora' else 'full fine-tune'} step (ViT frozen): "
+                                   f"fwd+bwd+AdamW, {'anyres 5 tiles, S=3056' if args.workload == 'anyres' else 'S=704'}, "
+                                   f"{args.batch} pairs/GPU/step", "global_batch": args.batch * world,
+                       "seq_len": 3056 if args.workload == "anyres" else 704,
                        "parallelism": f"dp{world}", "final_loss": final_loss},
             "roofline": roofline,
         }
