@@ -164,10 +164,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # rehearsal hook (tests only): RV_BENCH_REHEARSAL=1 runs all ranks on cuda:0 over gloo, because RCCL refuses two
+    # ranks on one device and the multi-GPU node is the driver's; the measured path always uses nccl (= RCCL)
+    rehearsal = os.environ.get("RV_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     pg = None
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
         pg = torch.distributed.group.WORLD
     geo = GEOMETRIES[args.geometry]
     kw = {}
