@@ -177,7 +177,13 @@ constexpr int B_RING_OFF = 6 * HALF_BYTES;
 // which makes the 8 rows a 32-lane half touches land on 8 different granules (conflict-free).
 DEVINL int tswz(int m) { return ((m & 3) | (((m >> 3) & 1) << 2)) << 1; }
 
-template <bool T>
+// PERM (B operand of the 256x256 kernel): LDS feature row 32a + 16j + c holds feature 32a + 8(c>>2) + 4j + (c&3), so the
+// two 16-row MFMA tiles j = 0,1 of a 32-row group interleave in units of 4 features and a lane's accumulators for the
+// pair are 8 CONSECUTIVE output columns (one 16-byte store per lane, 64-byte runs per row).  For transposed operands the
+// same interleave is a different column start of the tr read, no staging change.
+DEVINL int perm32f(int r) { return (r & ~31) + (((r & 15) >> 2) << 3) + (((r >> 4) & 1) << 2) + (r & 3); }
+
+template <bool T, bool PERM = false>
 DEVINL void stage_half(const bf16* __restrict__ src, long ld, int feat0, int nfeat, int k0, int K, const bf16* zeros,
                        char* lds, int wid, int lane) {
 #pragma unroll
@@ -188,7 +194,7 @@ DEVINL void stage_half(const bf16* __restrict__ src, long ld, int feat0, int nfe
         if (!T) {
             const int r = c >> 3, p = c & 7;
             const int lc = p ^ ((r >> 1) & 7);
-            const int gr = feat0 + r, gk = k0 + lc * 8;
+            const int gr = feat0 + (PERM ? perm32f(r) : r), gk = k0 + lc * 8;
             g = (gr < nfeat && gk < K) ? (src + (long)gr * ld + gk) : zeros;
         } else {
             const int r = c >> 4, p = c & 15;
@@ -210,14 +216,16 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 // names every destination, so no consumer is scheduled above it) -- guide section 5.7 form (ii).
 struct Frag { bf16x8 n; s16x4 t0, t1; };
 
-template <bool T>
+template <bool T, bool PERM = false>
 DEVINL void frag_issue(Frag& f, const char* tile, int fbase, int kk, int lane) {
     if (!T) { f.n = read_frag(tile, fbase + (lane & 15), kk * 4 + (lane >> 4)); return; }
     const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-    const int c16 = (fbase >> 3) + (p >> 1);
+    // the lane supplies the address of 4 consecutive features: fbase + 4p, or (PERM) 32a + 8p + 4j for tile j of group a
+    const int c16 = PERM ? ((fbase & ~31) >> 3) + p : (fbase >> 3) + (p >> 1);
+    const int half = PERM ? ((fbase >> 4) & 1) : (p & 1);
     const int m0 = kk * 32 + 8 * g + q, m1 = m0 + 4;
-    const char* a0 = tile + m0 * 256 + ((c16 ^ tswz(m0)) << 4) + ((p & 1) << 3);
-    const char* a1 = tile + m1 * 256 + ((c16 ^ tswz(m1)) << 4) + ((p & 1) << 3);
+    const char* a0 = tile + m0 * 256 + ((c16 ^ tswz(m0)) << 4) + (half << 3);
+    const char* a1 = tile + m1 * 256 + ((c16 ^ tswz(m1)) << 4) + (half << 3);
     const unsigned o0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)a0;
     const unsigned o1 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)a1;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.t0) : "v"(o0) : "memory");
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
 
     const int nt = (P.K + BK - 1) / BK;
     auto stageA = [&](int t, int slot, int h) { stage_half<TA>(P.A, P.lda, m0 + h * 128, P.M, t * BK, P.K, P.zeros, smem + (slot * 2 + h) * HALF_BYTES, wid, lane); };
-    auto stageB = [&](int t, int h) { stage_half<TB>(P.B, P.ldb, n0 + h * 128, P.N, t * BK, P.K, P.zeros, smem + B_RING_OFF + ((t & 1) * 2 + h) * HALF_BYTES, wid, lane); };
+    auto stageB = [&](int t, int h) { stage_half<TB, true>(P.B, P.ldb, n0 + h * 128, P.N, t * BK, P.K, P.zeros, smem + B_RING_OFF + ((t & 1) * 2 + h) * HALF_BYTES, wid, lane); };
 
     // prologue: tiles 0 and 1 (tile 1 stays in flight)
     stageA(0, 0, 0); stageA(0, 0, 1); stageB(0, 0); stageB(0, 1);
@@ -287,14 +295,14 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) frag_issue<TB>(fb[0][j][kk], Bt, brow0 + j * 16, kk, lane);
+            for (int j = 0; j < 2; ++j) frag_issue<TB, true>(fb[0][j][kk], Bt, brow0 + j * 16, kk, lane);
 #pragma unroll
             for (int i = 0; i < 4; ++i) frag_issue<TA>(fa[i][kk], At, i * 16, kk, lane);
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) frag_issue<TB>(fb[1][j][kk], Bt, brow0 + 32 + j * 16, kk, lane);
+            for (int j = 0; j < 2; ++j) frag_issue<TB, true>(fb[1][j][kk], Bt, brow0 + 32 + j * 16, kk, lane);
         constexpr int B1_OPS = TB ? 8 : 4;   // the B(nh1) prefetch stays in flight behind phase 1's MFMAs
         frag_wait4<TB, B1_OPS>(fb[0][0][0], fb[0][1][0], fb[0][0][1], fb[0][1][1]);
         frag_wait4<TA, B1_OPS>(fa[0][0], fa[1][0], fa[2][0], fa[3][0]);
@@ -372,44 +380,67 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
         BAR_LGKM();   // also: every wave's A reads of tile t are complete -> the A halves of this slot may be restaged
     }
 
-    // epilogue: lane holds C[m = m0 + wr*128 + i*16 + (lane&15)][n = n0 + wc*64 + j*16 + 4*(lane>>4) + r]
-    const bool n_vec_ok = (P.N % 4 == 0) && (P.ldc % 4 == 0);
+    // epilogue: with the interleaved B rows a lane holds, for m = m0 + wr*128 + i*16 + (lane&15), the 8 consecutive columns
+    // n = n0 + wc*64 + 32a + 8*(lane>>4) + {0..7}: acc[i][2a][0..3] then acc[i][2a+1][0..3]
+    const bool n_vec_ok = (P.N % 8 == 0) && (P.ldc % 8 == 0) && (!P.R || P.ldr % 8 == 0) &&
+                          ((((uintptr_t)P.C) | ((uintptr_t)P.R) | ((uintptr_t)P.bias)) & 15) == 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int m = m0 + wr * 128 + i * 16 + (lane & 15);
         if (m >= P.M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wc * 64 + j * 16 + 4 * (lane >> 4);
+        for (int a = 0; a < 2; ++a) {
+            const int n = n0 + wc * 64 + 32 * a + 8 * (lane >> 4);
             if (n >= P.N) continue;
-            float v[4] = {acc[i][j][0] * P.alpha, acc[i][j][1] * P.alpha, acc[i][j][2] * P.alpha, acc[i][j][3] * P.alpha};
-            const int nv = min(4, P.N - n);
-            if (P.bias) {
+            float v[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (r < nv) v[r] += bf2f(P.bias[n + r]);
+            for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * a][r] * P.alpha; v[4 + r] = acc[i][2 * a + 1][r] * P.alpha; }
+            const int nv = min(8, P.N - n);
+            const bool full = (nv == 8) && n_vec_ok;
+            if (P.bias) {
+                if (full) {
+                    const bf16x8 bb = *(const bf16x8*)(P.bias + n);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += bf2f(bb[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) if (r < nv) v[r] += bf2f(P.bias[n + r]);
+                }
             }
             if (P.act != RV_ACT_NONE) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], P.act);
+                for (int r = 0; r < 8; ++r) v[r] = apply_act(v[r], P.act);
             }
             if (P.R) {
                 if (P.res_f32) {
                     const float* rp = (const float*)P.R + (long)m * P.ldr + n;
+                    if (full) {
+                        const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) if (r < nv) v[r] += rp[r];
+                        for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) if (r < nv) v[r] += rp[r];
+                    }
                 } else {
                     const bf16* rp = (const bf16*)P.R + (long)m * P.ldr + n;
+                    if (full) {
+                        const bf16x8 rr = *(const bf16x8*)rp;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) if (r < nv) v[r] += bf2f(rp[r]);
+                        for (int r = 0; r < 8; ++r) v[r] += bf2f(rr[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) if (r < nv) v[r] += bf2f(rp[r]);
+                    }
                 }
             }
             if (P.out_f32) {
                 float* cp = (float*)P.C + (long)m * P.ldc + n;
-                if (nv == 4 && n_vec_ok) *(f32x4*)cp = f32x4{v[0], v[1], v[2], v[3]};
+                if (full) { *(f32x4*)cp = f32x4{v[0], v[1], v[2], v[3]}; *(f32x4*)(cp + 4) = f32x4{v[4], v[5], v[6], v[7]}; }
                 else for (int r = 0; r < nv; ++r) cp[r] = v[r];
             } else {
                 bf16* cp = (bf16*)P.C + (long)m * P.ldc + n;
-                if (nv == 4 && n_vec_ok) *(bf16x4*)cp = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+                if (full) *(bf16x8*)cp = bf16x8{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3]), f2bf(v[4]), f2bf(v[5]), f2bf(v[6]), f2bf(v[7])};
                 else for (int r = 0; r < nv; ++r) cp[r] = f2bf(v[r]);
             }
         }
