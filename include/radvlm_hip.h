@@ -44,6 +44,16 @@ int rv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void
 int rv_gemm_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
                  const void* residual, int64_t ldr, int M, int N, int K, int trans_a, int trans_b, float alpha, int act,
                  int out_f32, int res_f32, const void* zeros16, void* stream);
+/* Extended form:  C = act(alpha * (op(A) op(B)^T + op(A2) op(B2)^T) + bias) + residual.
+ *  - (A2, B2, K2): optional second operand pair sharing the transposition flags -- the fused LoRA GEMM
+ *    y = [x | t] [W | B]^T (forward) and dx = [dy | dt] [W ; A] (dgrad) of peft's LoraLayer (train/train.py:1515-1532)
+ *    in one launch, without a second pass over y.  NULL / 0 disables it.
+ *  - workspace (optional fp32 scratch): lets outputs with few tiles and a long contraction (LoRA dA/dB) run split-K over
+ *    the idle CUs; partial sums are combined by a deterministic reduce kernel (no atomics). */
+int rv_gemm_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
+                    const void* residual, int64_t ldr, int M, int N, int K, int trans_a, int trans_b, float alpha, int act,
+                    int out_f32, int res_f32, const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int K2,
+                    void* workspace, int64_t workspace_bytes, const void* zeros16, void* stream);
 /* Tuning hook: 0 = automatic tile selection (default), 1 = 128x128 tile kernel, 2 = 256x256 tile kernel. */
 int rv_gemm_select_kernel(int which);
 

@@ -26,6 +26,10 @@ struct GemmParams {
     long lda, ldb, ldc, ldr;
     int M, N, K, act, out_f32, res_f32, tiles_m, tiles_n;
     float alpha;
+    // MODE 1 (fused second operand pair, e.g. the LoRA path  [x | t] [W | B]^T):  C += A2[M,K2] * B2[N,K2]^T
+    const bf16* A2; const bf16* B2; long lda2, ldb2; int K2;
+    // MODE 2 (split-K for outputs with few tiles): block = (tile, slice); raw fp32 partials go to ws[slice][M][N]
+    float* ws; int splits;
 };
 
 DEVINL float apply_act(float x, int act) {
@@ -248,14 +252,15 @@ DEVINL bf16x8 frag_get(const Frag& f) {
 
 #define BAR_LGKM() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-template <bool TA, bool TB>
+template <bool TA, bool TB, int MODE>
 __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wid = wave_id(), lane = lane_id();
     const int wr = wid >> 2, wc = wid & 3;
 
     const int nwg = P.tiles_m * P.tiles_n;
-    int pid = xcd_remap(blockIdx.x, nwg);
+    const int kslice = MODE == 2 ? (int)blockIdx.x % P.splits : 0;
+    int pid = xcd_remap(MODE == 2 ? (int)blockIdx.x / P.splits : (int)blockIdx.x, nwg);
     constexpr int GROUP_M = 4;
     const int per_group = GROUP_M * P.tiles_n;
     const int group = pid / per_group;
@@ -271,9 +276,20 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nt = (P.K + BK - 1) / BK;
-    auto stageA = [&](int t, int slot, int h) { stage_half<TA>(P.A, P.lda, m0 + h * 128, P.M, t * BK, P.K, P.zeros, smem + (slot * 2 + h) * HALF_BYTES, wid, lane); };
-    auto stageB = [&](int t, int h) { stage_half<TB, true>(P.B, P.ldb, n0 + h * 128, P.N, t * BK, P.K, P.zeros, smem + B_RING_OFF + ((t & 1) * 2 + h) * HALF_BYTES, wid, lane); };
+    // K-tile steps of this block: the whole K (MODE 0), K then K2 (MODE 1), or this block's slice of K (MODE 2)
+    const int nt1 = (P.K + BK - 1) / BK;
+    const int t0 = MODE == 2 ? (int)((long)kslice * nt1 / P.splits) : 0;
+    const int nt = MODE == 2 ? (int)((long)(kslice + 1) * nt1 / P.splits) - t0 : (MODE == 1 ? nt1 + (P.K2 + BK - 1) / BK : nt1);
+    auto stageA = [&](int t, int slot, int h) {
+        char* dst = smem + (slot * 2 + h) * HALF_BYTES;
+        if (MODE == 1 && t >= nt1) stage_half<TA>(P.A2, P.lda2, m0 + h * 128, P.M, (t - nt1) * BK, P.K2, P.zeros, dst, wid, lane);
+        else stage_half<TA>(P.A, P.lda, m0 + h * 128, P.M, (t0 + t) * BK, P.K, P.zeros, dst, wid, lane);
+    };
+    auto stageB = [&](int t, int h) {
+        char* dst = smem + B_RING_OFF + ((t & 1) * 2 + h) * HALF_BYTES;
+        if (MODE == 1 && t >= nt1) stage_half<TB, true>(P.B2, P.ldb2, n0 + h * 128, P.N, (t - nt1) * BK, P.K2, P.zeros, dst, wid, lane);
+        else stage_half<TB, true>(P.B, P.ldb, n0 + h * 128, P.N, (t0 + t) * BK, P.K, P.zeros, dst, wid, lane);
+    };
 
     // prologue: tiles 0 and 1 (tile 1 stays in flight)
     stageA(0, 0, 0); stageA(0, 0, 1); stageB(0, 0); stageB(0, 1);
@@ -393,6 +409,12 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
             const int n = n0 + wc * 64 + 32 * a + 8 * (lane >> 4);
             if (n >= P.N) continue;
             float v[8];
+            if (MODE == 2) {   // raw partial sums; alpha / bias / act / residual are applied by the reduce kernel
+                float* wp = P.ws + ((long)kslice * P.M + m) * P.N + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { if (n + r < P.N) wp[r] = acc[i][2 * a][r]; if (n + 4 + r < P.N) wp[4 + r] = acc[i][2 * a + 1][r]; }
+                continue;
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * a][r] * P.alpha; v[4 + r] = acc[i][2 * a + 1][r] * P.alpha; }
             const int nv = min(8, P.N - n);
@@ -447,30 +469,62 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
     }
 }
 
+// C = act(alpha * sum_s ws[s] + bias) + residual  (finishes a split-K GEMM)
+__global__ void splitk_reduce_kernel(GemmParams P) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)P.M * P.N;
+    if (i >= total) return;
+    const int m = (int)(i / P.N), n = (int)(i % P.N);
+    float s = 0.f;
+    for (int k = 0; k < P.splits; ++k) s += P.ws[(long)k * total + i];
+    s *= P.alpha;
+    if (P.bias) s += bf2f(P.bias[n]);
+    s = apply_act(s, P.act);
+    if (P.R) s += P.res_f32 ? ((const float*)P.R)[(long)m * P.ldr + n] : bf2f(((const bf16*)P.R)[(long)m * P.ldr + n]);
+    if (P.out_f32) ((float*)P.C)[(long)m * P.ldc + n] = s;
+    else ((bf16*)P.C)[(long)m * P.ldc + n] = f2bf(s);
+}
+
 }  // namespace
 
 static int g_force_kernel = 0;  // 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel (RV_GEMM_KERNEL or rv_gemm_select_kernel)
 extern "C" int rv_gemm_select_kernel(int which) { g_force_kernel = which; return RV_OK; }
 
-template <bool TA, bool TB>
-static void launch256(const GemmParams& P, hipStream_t st) {
+template <bool TA, bool TB, int MODE>
+static void launch256m(const GemmParams& P, hipStream_t st) {
     static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)gemm_kernel_256<TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2); set = true; }
-    hipLaunchKernelGGL((gemm_kernel_256<TA, TB>), dim3(P.tiles_m * P.tiles_n), dim3(512), LDS_BYTES2, st, P);
+    if (!set) { (void)hipFuncSetAttribute((const void*)gemm_kernel_256<TA, TB, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2); set = true; }
+    const int blocks = P.tiles_m * P.tiles_n * (MODE == 2 ? P.splits : 1);
+    hipLaunchKernelGGL((gemm_kernel_256<TA, TB, MODE>), dim3(blocks), dim3(512), LDS_BYTES2, st, P);
+    if (MODE == 2) {
+        const long total = (long)P.M * P.N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P);
+    }
+}
+template <bool TA, bool TB>
+static void launch256(const GemmParams& P, int mode, hipStream_t st) {
+    if (mode == 1) launch256m<TA, TB, 1>(P, st);
+    else if (mode == 2) launch256m<TA, TB, 2>(P, st);
+    else launch256m<TA, TB, 0>(P, st);
 }
 
-extern "C" int rv_gemm_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
-                            const void* residual, int64_t ldr, int M, int N, int K, int trans_a, int trans_b, float alpha,
-                            int act, int out_f32, int res_f32, const void* zeros16, void* stream) {
+extern "C" int rv_gemm_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
+                               const void* residual, int64_t ldr, int M, int N, int K, int trans_a, int trans_b, float alpha,
+                               int act, int out_f32, int res_f32, const void* A2, int64_t lda2, const void* B2, int64_t ldb2,
+                               int K2, void* workspace, int64_t workspace_bytes, const void* zeros16, void* stream) {
     if (!A || !B || !C || !zeros16 || M <= 0 || N <= 0 || K <= 0) return RV_ERR_ARG;
     if ((lda & 7) || (ldb & 7)) return RV_ERR_ARG;
     if ((!trans_a && (K & 7)) || (trans_a && (M & 7)) || (!trans_b && (K & 7)) || (trans_b && (N & 7))) return RV_ERR_ARG;
     if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)zeros16) & 15) return RV_ERR_ARG;
+    const bool ext = A2 && B2 && K2 > 0;
+    if (ext && ((lda2 & 7) || (ldb2 & 7) || (!trans_a && (K2 & 7)) || (!trans_b && (K2 & 7)) || (((uintptr_t)A2 | (uintptr_t)B2) & 15))) return RV_ERR_ARG;
     GemmParams P;
     P.A = (const bf16*)A; P.B = (const bf16*)B; P.C = C; P.bias = (const bf16*)bias; P.R = residual;
     P.zeros = (const bf16*)zeros16;
     P.lda = lda; P.ldb = ldb; P.ldc = ldc; P.ldr = ldr;
     P.M = M; P.N = N; P.K = K; P.act = act; P.out_f32 = out_f32; P.res_f32 = res_f32; P.alpha = alpha;
+    P.A2 = (const bf16*)A2; P.B2 = (const bf16*)B2; P.lda2 = lda2; P.ldb2 = ldb2; P.K2 = ext ? K2 : 0;
+    P.ws = (float*)workspace; P.splits = 1;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES);
@@ -479,19 +533,35 @@ extern "C" int rv_gemm_bf16(const void* A, int64_t lda, const void* B, int64_t l
         attr_set = true;
     }
     const long tiles256 = (long)((M + BM2 - 1) / BM2) * ((N + BN2 - 1) / BN2);
+    const int nt = (K + BK - 1) / BK;
     const int force = g_force_kernel;
-    // the 128x128 kernel only exists for the NT form; transposed operands always take the 256x256 kernel
-    const bool use256 = (trans_a || trans_b) ? true : (force ? (force == 2) : (tiles256 >= 200));
+    // split-K: few output tiles but a long contraction (LoRA / bias-like gradients): spread K over the idle CUs
+    int mode = ext ? 1 : 0;
+    if (!ext && workspace && tiles256 <= 64 && nt >= 16) {
+        int sp = (int)(256 / tiles256);
+        if (sp > nt / 4) sp = nt / 4;
+        if (sp > 32) sp = 32;
+        if (sp >= 2 && (int64_t)sp * M * N * 4 <= workspace_bytes) { mode = 2; P.splits = sp; }
+    }
+    // the 128x128 kernel only exists for the plain NT form
+    const bool use256 = (trans_a || trans_b || mode) ? true : (force ? (force == 2) : (tiles256 >= 200));
     hipStream_t st = (hipStream_t)stream;
     if (use256) {
         P.tiles_m = (M + BM2 - 1) / BM2; P.tiles_n = (N + BN2 - 1) / BN2;
-        if (trans_a) { if (trans_b) launch256<true, true>(P, st); else launch256<true, false>(P, st); }
-        else { if (trans_b) launch256<false, true>(P, st); else launch256<false, false>(P, st); }
+        if (trans_a) { if (trans_b) launch256<true, true>(P, mode, st); else launch256<true, false>(P, mode, st); }
+        else { if (trans_b) launch256<false, true>(P, mode, st); else launch256<false, false>(P, mode, st); }
     } else {
         P.tiles_m = (M + BM - 1) / BM; P.tiles_n = (N + BN - 1) / BN;
         hipLaunchKernelGGL(gemm_nt_kernel, dim3(P.tiles_m * P.tiles_n), dim3(256), NSTAGE * STAGE_BYTES, st, P);
     }
     return rv_check_launch();
+}
+
+extern "C" int rv_gemm_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
+                            const void* residual, int64_t ldr, int M, int N, int K, int trans_a, int trans_b, float alpha,
+                            int act, int out_f32, int res_f32, const void* zeros16, void* stream) {
+    return rv_gemm_bf16_ex(A, lda, B, ldb, C, ldc, bias, residual, ldr, M, N, K, trans_a, trans_b, alpha, act, out_f32, res_f32,
+                           nullptr, 0, nullptr, 0, 0, nullptr, 0, zeros16, stream);
 }
 
 extern "C" int rv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,

@@ -309,23 +309,27 @@ class LlavaEngine:
             lv = self._layer_views(i)
             h1, rstd1 = ops.rmsnorm_fwd(x, lv["ln1"], self.eps)
             sv = {}
-            qkv = ops.gemm_nt(h1, lv["qkv"])
             if self.lora:
-                self._lora_fwd(h1, qkv, i, (("self_attn.q_proj", 0, d), ("self_attn.k_proj", d, 2 * d), ("self_attn.v_proj", 2 * d, 3 * d)), sv)
+                qkv = self._lora_linear(h1, lv["qkv"], i, self._MODS_QKV(d), sv)
+            else:
+                qkv = ops.gemm_nt(h1, lv["qkv"])
             ops.rope_inplace(qkv, cs, S, H, hd, 2, 1)
             vT = ops.transpose_heads(qkv[:, 2 * d:], B, S, H, hd, s_pad)
             attn, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], vT, B, S, H, hd, s_pad, causal=True, lens=lens)
-            x_mid = ops.gemm_nt(attn, lv["o"], residual=x)
             if self.lora:
-                self._lora_fwd(attn, x_mid, i, (("self_attn.o_proj", 0, d),), sv)
+                x_mid = self._lora_linear(attn, lv["o"], i, (("self_attn.o_proj", 0, d),), sv, residual=x)
+            else:
+                x_mid = ops.gemm_nt(attn, lv["o"], residual=x)
             h2, rstd2 = ops.rmsnorm_fwd(x_mid, lv["ln2"], self.eps)
-            gu = ops.gemm_nt(h2, lv["gu"])
             if self.lora:
-                self._lora_fwd(h2, gu, i, (("mlp.gate_proj", 0, F), ("mlp.up_proj", F, 2 * F)), sv)
+                gu = self._lora_linear(h2, lv["gu"], i, (("mlp.gate_proj", 0, F), ("mlp.up_proj", F, 2 * F)), sv)
+            else:
+                gu = ops.gemm_nt(h2, lv["gu"])
             act = ops.swiglu_fwd(gu, F)
-            x_out = ops.gemm_nt(act, lv["down"], residual=x_mid)
             if self.lora:
-                self._lora_fwd(act, x_out, i, (("mlp.down_proj", 0, d),), sv)
+                x_out = self._lora_linear(act, lv["down"], i, (("mlp.down_proj", 0, d),), sv, residual=x_mid)
+            else:
+                x_out = ops.gemm_nt(act, lv["down"], residual=x_mid)
             layers.append(dict(x=x, rstd1=rstd1, h1=h1, qkv=qkv, attn=attn, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2,
                                gu=gu, act=act, lora=sv))
             x = x_out
@@ -371,44 +375,60 @@ class LlavaEngine:
         k = [t for t, _, _ in LORA_TARGETS].index(lname)
         return (self.lora_step * 1000003 + i * 131 + k) & 0x7FFFFFFFFFFFFFFF
 
-    def _lora_fwd(self, x, y, i, mods, saved):
-        """y[:, c0:c1] += (alpha/r) * dropout(x) A^T B^T for every adapted module writing columns [c0, c1) of y."""
+    @staticmethod
+    def _MODS_QKV(d):
+        return (("self_attn.q_proj", 0, d), ("self_attn.k_proj", d, 2 * d), ("self_attn.v_proj", 2 * d, 3 * d))
+
+    def _lora_ws(self):
+        if getattr(self, "_ws", None) is None:
+            self._ws = torch.empty(32 << 20, dtype=torch.float32, device=self.device)   # split-K scratch (128 MiB)
+        return self._ws
+
+    def _lora_linear(self, x, w, i, mods, saved, residual=None):
+        """y[:, c0:c1] = x W[c0:c1]^T + t B^T (+ residual) with t = (alpha/r) dropout(x) A^T: ONE launch per adapted module,
+        the adapter rides the main GEMM as a second operand pair (K + r), no second pass over y."""
+        y = torch.empty(x.shape[0], w.shape[0], dtype=BF16, device=self.device)
         for lname, c0, c1 in mods:
             pre = f"model.layers.{i}.{lname}."
             A, B = self.W(pre + "lora_A.weight"), self.W(pre + "lora_B.weight")
             xd = ops.dropout(x, self.lora_p, self._lora_seed(i, lname)) if self.lora_p > 0 else x
-            t = ops.gemm_nt(xd, A)
-            ys = y[:, c0:c1]
-            ops.gemm(t, B, out=ys, residual=ys, alpha=self.lora_scale)
+            t = ops.gemm(xd, A, alpha=self.lora_scale)
+            ops.gemm(x, w[c0:c1], out=y[:, c0:c1], residual=None if residual is None else residual[:, c0:c1], a2=t, b2=B)
             saved[lname] = t
+        return y
 
-    def _lora_bwd(self, dy, x, i, mods, saved, dx):
-        """Adapter gradients and the adapter path's contribution to dx (dx already holds dY W of the frozen weight)."""
+    def _lora_linear_bwd(self, dy, x, w, i, mods, saved):
+        """dx = sum_j dy_j W_j + (adapter path); dA, dB into the flat grad views (split-K: r-wide outputs, token-long K)."""
         acc = self.grad_accum_started
+        ws = self._lora_ws()
+        dx = None
         for lname, c0, c1 in mods:
             pre = f"model.layers.{i}.{lname}."
             A, B = self.W(pre + "lora_A.weight"), self.W(pre + "lora_B.weight")
             gA, gB = self.G(pre + "lora_A.weight"), self.G(pre + "lora_B.weight")
             dyj = dy[:, c0:c1]
-            t = saved[lname]
-            dt = ops.gemm(dyj, B, tb=True, alpha=self.lora_scale)
-            ops.gemm(dyj, t, ta=True, tb=True, out=gB, residual=gB if acc else None, alpha=self.lora_scale)
+            t = saved[lname]                                        # already scaled by alpha/r
+            dts = ops.gemm(dyj, B, tb=True, alpha=self.lora_scale)    # d(dropout(x) A^T)
+            ops.gemm(dyj, t, ta=True, tb=True, out=gB, residual=gB if acc else None, workspace=ws)
+            first = dx is None
+            if first:
+                dx = torch.empty(x.shape[0], w.shape[1], dtype=BF16, device=self.device)
             if self.lora_p > 0:
                 seed = self._lora_seed(i, lname)
-                xd = ops.dropout(x, self.lora_p, seed)
-                ops.gemm(dt, xd, ta=True, tb=True, out=gA, residual=gA if acc else None)
-                tmp = ops.dropout(ops.gemm(dt, A, tb=True), self.lora_p, seed)
+                ops.gemm(dts, ops.dropout(x, self.lora_p, seed), ta=True, tb=True, out=gA, residual=gA if acc else None, workspace=ws)
+                ops.gemm(dyj, w[c0:c1], tb=True, out=dx, residual=None if first else dx)
+                tmp = ops.dropout(ops.gemm(dts, A, tb=True), self.lora_p, seed)
                 from . import lib
                 lib.call("rv_add_bf16", dx, tmp, dx, dx.numel())
             else:
-                ops.gemm(dt, x, ta=True, tb=True, out=gA, residual=gA if acc else None)
-                ops.gemm(dt, A, tb=True, out=dx, residual=dx)
+                ops.gemm(dts, x, ta=True, tb=True, out=gA, residual=gA if acc else None, workspace=ws)
+                ops.gemm(dyj, w[c0:c1], tb=True, out=dx, residual=None if first else dx, a2=dts, b2=A)
+        return dx
 
     def _lm_linear_bwd(self, dy, x, w, gw, i, mods, saved):
-        dx = self._linear_bwd(dy, x, w, None if self.lora else gw)
         if self.lora:
-            self._lora_bwd(dy, x, i, mods, saved, dx)
-        return dx
+            return self._lora_linear_bwd(dy, x, w, i, mods, saved)
+        return self._linear_bwd(dy, x, w, gw)
 
     def backward(self):
         """Backward of the last forward(); gradients land in self.grads (bf16, flat)."""
@@ -442,8 +462,7 @@ class LlavaEngine:
             ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a["attn"], dattn, a["lse"], B, S, H, hd, s_pad, True,
                          lens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:])
             ops.rope_inplace(dqkv, cs, S, H, hd, 2, -1)
-            dh1 = self._lm_linear_bwd(dqkv, a["h1"], lv["qkv"], gv.get("qkv"), i,
-                                      (("self_attn.q_proj", 0, d), ("self_attn.k_proj", d, 2 * d), ("self_attn.v_proj", 2 * d, 3 * d)), sv)
+            dh1 = self._lm_linear_bwd(dqkv, a["h1"], lv["qkv"], gv.get("qkv"), i, self._MODS_QKV(d), sv)
             ops.rmsnorm_bwd(dh1, a["x"], lv["ln1"], a["rstd1"], dx=dx, dx_add=True, dw=gv.get("ln1"), dw_accumulate=acc)
             c["layers"][i] = None  # free this layer's activations
             p = f"model.layers.{i}."

@@ -44,7 +44,8 @@ def gemm_nt(a, b, out=None, bias=None, residual=None, act=ACT_NONE, out_dtype=BF
     return out
 
 
-def gemm(a, b, ta=False, tb=False, out=None, bias=None, residual=None, act=ACT_NONE, out_dtype=BF16, alpha=1.0):
+def gemm(a, b, ta=False, tb=False, out=None, bias=None, residual=None, act=ACT_NONE, out_dtype=BF16, alpha=1.0, a2=None, b2=None,
+         workspace=None):
     """out[M,N] = act(op(a) @ op(b)^T + bias) + residual with a stored [K,M] if ta else [M,K], b stored [K,N] if tb else [N,K]."""
     _chk(a), _chk(b)
     assert a.stride(1) == 1 and b.stride(1) == 1
@@ -60,8 +61,22 @@ def gemm(a, b, ta=False, tb=False, out=None, bias=None, residual=None, act=ACT_N
         res_f32, ldr = int(residual.dtype == torch.float32), residual.stride(0)
     if bias is not None:
         assert bias.numel() == N and bias.is_contiguous()
-    lib.call("rv_gemm_bf16", a, a.stride(0), b, b.stride(0), out, out.stride(0), bias, residual, ldr, M, N, K, int(ta), int(tb),
-             float(alpha), act, int(out.dtype == torch.float32), res_f32, lib.zeros16(a.device))
+    if a2 is None and workspace is None:
+        lib.call("rv_gemm_bf16", a, a.stride(0), b, b.stride(0), out, out.stride(0), bias, residual, ldr, M, N, K, int(ta), int(tb),
+                 float(alpha), act, int(out.dtype == torch.float32), res_f32, lib.zeros16(a.device))
+        return out
+    # fused second operand pair (a2 like a, b2 like b, contraction K2) and/or split-K scratch
+    K2 = 0
+    if a2 is not None:
+        _chk(a2), _chk(b2)
+        assert a2.stride(1) == 1 and b2.stride(1) == 1
+        (K2, M2) = a2.shape if ta else a2.shape[::-1]
+        (K2b, N2) = b2.shape if tb else b2.shape[::-1]
+        assert M2 == M and N2 == N and K2 == K2b
+    ws_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
+    lib.call("rv_gemm_bf16_ex", a, a.stride(0), b, b.stride(0), out, out.stride(0), bias, residual, ldr, M, N, K, int(ta), int(tb),
+             float(alpha), act, int(out.dtype == torch.float32), res_f32, a2, a2.stride(0) if a2 is not None else 0, b2,
+             b2.stride(0) if b2 is not None else 0, K2, workspace, ws_bytes, lib.zeros16(a.device))
     return out
 
 

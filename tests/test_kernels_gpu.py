@@ -343,3 +343,28 @@ def test_dropout_and_alpha(ops):
     a, b = rnd(61, (96, 64)).cuda(), rnd(62, (80, 64)).cuda()
     out = ops.gemm(a, b, alpha=0.25, out_dtype=torch.float32)
     assert relerr(out, 0.25 * (a.float().cpu() @ b.float().cpu().t())) < 1e-5
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
+def test_gemm_fused_pair_and_splitk(ops, ta, tb):
+    """rv_gemm_bf16_ex: second operand pair (the fused LoRA GEMM) and split-K with a deterministic reduce."""
+    M, N, K, K2 = 304, 520, 256, 64
+    a, b, a2, b2 = rnd(70, (M, K)), rnd(71, (N, K)), rnd(72, (M, K2)), rnd(73, (N, K2))
+    res = rnd(74, (M, N))
+    ref = a.float() @ b.float().t() + a2.float() @ b2.float().t()
+    put = lambda t, tr: (t.t().contiguous() if tr else t).cuda()
+    out = ops.gemm(put(a, ta), put(b, tb), ta=ta, tb=tb, a2=put(a2, ta), b2=put(b2, tb), out_dtype=torch.float32)
+    assert relerr(out, ref) < 1e-5
+    out = ops.gemm(put(a, ta), put(b, tb), ta=ta, tb=tb, a2=put(a2, ta), b2=put(b2, tb), residual=res.cuda(), alpha=0.5)
+    assert relerr(out, 0.5 * ref + res.float()) < TOL
+    # split-K: 64 x 520 output (3 tiles), contraction 4096 -> sliced over the idle CUs
+    Ms, Ks = 64, 4096
+    a, b = rnd(75, (Ms, Ks)), rnd(76, (N, Ks))
+    ref = a.float() @ b.float().t()
+    ws = torch.empty(8 << 20, dtype=torch.float32, device="cuda")
+    r0 = rnd(77, (Ms, N)).cuda()
+    out = ops.gemm(put(a, ta), put(b, tb), ta=ta, tb=tb, workspace=ws, out_dtype=torch.float32, alpha=0.25)
+    assert relerr(out, 0.25 * ref) < 1e-5
+    out2 = ops.gemm(put(a, ta), put(b, tb), ta=ta, tb=tb, workspace=ws, residual=r0)
+    assert relerr(out2, ref + r0.float().cpu()) < TOL
+    assert torch.equal(out, ops.gemm(put(a, ta), put(b, tb), ta=ta, tb=tb, workspace=ws, out_dtype=torch.float32, alpha=0.25))
