@@ -544,7 +544,13 @@ extern "C" int rv_gemm_bf16_ex(const void* A, int64_t lda, const void* B, int64_
         if (sp >= 2 && (int64_t)sp * M * N * 4 <= workspace_bytes) { mode = 2; P.splits = sp; }
     }
     // the 128x128 kernel only exists for the plain NT form
-    const bool use256 = (trans_a || trans_b || mode) ? true : (force ? (force == 2) : (tiles256 >= 200));
+    // tile-shape choice for the plain NT form: whole rounds of 256 CUs (256^2 tiles, 1 block/CU) against double-rounds of
+    // 512 blocks (128^2 tiles, 2 blocks/CU, ~15 % less efficient per flop but finer grained); measured crossover on
+    // MI355X (tools/ab_kernel12.py): 292 / 352 tiles -> 128^2 wins by 8-27 %, >= 876 tiles -> 256^2 wins by 3-7 %.
+    const long tiles128 = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const double cost256 = 4.0 * (double)((tiles256 + 255) / 256);
+    const double cost128 = 2.0 * 1.15 * (double)((tiles128 + 511) / 512);
+    const bool use256 = (trans_a || trans_b || mode) ? true : (force ? (force == 2) : (cost256 <= cost128));
     hipStream_t st = (hipStream_t)stream;
     if (use256) {
         P.tiles_m = (M + BM2 - 1) / BM2; P.tiles_n = (N + BN2 - 1) / BN2;
