@@ -247,3 +247,50 @@ def test_toy_lora(golden_dir):
     assert np.isfinite(float(l2)) and bool(torch.isfinite(eng2.lm.flat.float()).all())
     ad, oth = eng2.lora_state_dict()
     assert "base_model.model.model.layers.0.self_attn.q_proj.lora_A.default.weight" in ad and "model.mm_projector.0.weight" in oth
+
+
+def test_full_width_7b_layer_geometry():
+    """BASELINE config-2 widths (d=4096, 32 heads x 128, ffn=11008; ViT-L/14-336 widths) at reduced depth (1 decoder layer,
+    2 ViT layers, vocab 2048) so that the CPU oracle finishes in seconds: exercises the 256x256 GEMM in all operand forms,
+    hd=128 causal attention at S=704 and the 577-token ViT attention at their real sizes."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import llava_oracle as O
+    from radvlm_amd.engine import LlavaEngine
+    geo = {"vision": dict(d=1024, heads=16, ffn=4096, layers=3, image=336, patch=14),
+           "lm": dict(d=4096, heads=32, ffn=11008, layers=1, vocab=2048)}
+    g = torch.Generator().manual_seed(5)
+    B, T = 2, 129
+    ids = torch.randint(3, 2048, (B, T), generator=g)
+    labels = ids.clone()
+    labels[:, :64] = -100
+    ids[:, 35] = -200
+    labels[:, 35] = -100
+    ids[1, 100:] = 0
+    labels[1, 100:] = -100
+    mask = torch.ones(B, T, dtype=torch.bool)
+    mask[1, 100:] = False                                # second sample is shorter -> key-padding path
+    images = [torch.randn(3, 336, 336, generator=g).to(torch.bfloat16).float() for _ in range(B)]
+    eng = LlavaEngine(geo, device="cuda:0", init="fast", seed=3)
+    loss = eng.forward(ids.numpy(), mask.numpy(), labels.numpy(), images, want_logits=True)
+    logits = eng.last_logits.cpu()
+    plan_mask = torch.from_numpy(eng.ctx["plan"]["attention_mask"])
+    eng.backward()
+    torch.cuda.synchronize()
+    P = {k: v.float().cpu() for k, v in eng.state_dict().items()}
+    for k, v in P.items():
+        if "vision_tower" not in k:
+            v.requires_grad_(True)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    rl, rlog, aux = O.llava_forward(P, geo, ids, mask, labels, images)
+    rl.backward()
+    assert aux["inputs_embeds"].shape[1] == 704
+    assert abs(float(loss) - float(rl)) < 1e-2, (float(loss), float(rl))
+    ref = rlog.detach()[plan_mask]
+    assert float((logits[plan_mask] - ref).abs().max() / ref.abs().max()) < 3e-2
+    for k in ("lm_head.weight", "model.layers.0.mlp.down_proj.weight", "model.layers.0.mlp.gate_proj.weight",
+              "model.layers.0.self_attn.q_proj.weight", "model.layers.0.self_attn.v_proj.weight", "model.layers.0.self_attn.o_proj.weight",
+              "model.layers.0.input_layernorm.weight", "model.mm_projector.0.weight", "model.mm_projector.2.bias", "model.embed_tokens.weight"):
+        got, want = eng.G(k).float().cpu(), P[k].grad
+        rel = float((got - want).norm() / want.norm())
+        assert rel < 6e-2, (k, rel)
