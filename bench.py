@@ -221,7 +221,8 @@ def main():
         step()
         gflops, gms, nlaunch = gt.summary()
     roofline = {"bound": "mfma", "kernel": "gemm_kernel_256 (all operand forms; 128x128 kernel for small shapes)", "achieved": gflops / (gms * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS,
-                "unit": "TFLOP/s", "traffic": None, "launches_per_step": nlaunch, "gemm_ms_per_step": gms}
+                "unit": "TFLOP/s", "traffic": None, "launches_per_step": nlaunch, "gemm_ms_per_step": gms,
+                "algorithmic_flops_per_launch": gflops / max(1, nlaunch), "avg_launch_us": gms * 1e3 / max(1, nlaunch)}
     roofline["frac"] = roofline["achieved"] / roofline["peak"]
     try:  # HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE)
         with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm_hbm_traffic.json")) as f:

@@ -108,7 +108,7 @@ int rv_rope_inplace(void* x, int64_t ld, const float* cos_sin, int rows, int S, 
 int rv_attn_fwd(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* vT, void* out, int64_t ld_o,
                 float* lse, const int32_t* lens, int B, int H, int S, int S_pad, int hd, int causal, float scale,
                 const void* zeros16, void* stream);
-/* Backward of the above: delta = rowsum(dO*O); dQ (query-block pass), dK/dV (key-block pass).
+/* Backward of the above: dQ (query-block pass, which also produces delta = rowsum(dO*O)), then dK/dV (key-block pass).
  * qT/kT/doT are [b,h,hd,S_pad] transposed copies of q, k, dout (rv_transpose_bf16). */
 int rv_attn_bwd(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v, const void* o,
                 int64_t ld_o, const void* dout, int64_t ld_do, const void* qT, const void* kT, const void* doT,

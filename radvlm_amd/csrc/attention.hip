@@ -190,25 +190,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
-__global__ void attn_delta_kernel(AttnParams P, int HD) {
-    // one wave per (token row, head)
-    const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = lane_id();
-    const int total = P.B * P.S * P.H;
-    if (wid >= total) return;
-    const int h = wid % P.H, row = wid / P.H;
-    const bf16* o = P.o + (long)row * P.ld_o + h * HD;
-    const bf16* d = P.dout + (long)row * P.ld_do + h * HD;
-    float acc = 0.f;
-    for (int e = lane * 2; e < HD; e += 128) {
-        const bf16x2 a = *(const bf16x2*)(o + e), bb = *(const bf16x2*)(d + e);
-        acc += bf2f(a[0]) * bf2f(bb[0]) + bf2f(a[1]) * bf2f(bb[1]);
-    }
-    acc = wave_sum(acc);
-    const int b = row / P.S, s = row % P.S;
-    if (lane == 0) P.delta[(long)(b * P.H + h) * P.S_pad + s] = acc;
-}
-
 // ------------------------------------------------------------------------------------------------ backward: dQ
 template <int HD, bool CAUSAL, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dq_kernel(AttnParams P) {
@@ -228,10 +209,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dq_kernel(AttnParams
         const int row = min(q0 + qs * 16 + c, S - 1);
         const bf16* p = P.q + (long)(b * S + row) * P.ld_q + h * HD + g * 8;
         const bf16* d = P.dout + (long)(b * S + row) * P.ld_do + h * HD + g * 8;
+        const bf16* op = P.o + (long)(b * S + row) * P.ld_o + h * HD + g * 8;
+        float dsum = 0.f;   // delta = rowsum(dO * O), fused here (this lane owns 8 * KS of the row's HD products)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { qf[qs][ks] = *(const bf16x8*)(p + ks * 32); dof[qs][ks] = *(const bf16x8*)(d + ks * 32); }
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[qs][ks] = *(const bf16x8*)(p + ks * 32);
+            dof[qs][ks] = *(const bf16x8*)(d + ks * 32);
+            const bf16x8 ov = *(const bf16x8*)(op + ks * 32);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dsum += bf2f(ov[j]) * bf2f(dof[qs][ks][j]);
+        }
+        dsum += __shfl_xor(dsum, 16, 64);
+        dsum += __shfl_xor(dsum, 32, 64);
         lse2[qs] = P.lse[(long)(b * P.H + h) * P.S_pad + row] * LOG2E;
-        dl[qs] = P.delta[(long)(b * P.H + h) * P.S_pad + row];
+        dl[qs] = dsum;
+        if (g == 0 && q0 + qs * 16 + c < S) P.delta[(long)(b * P.H + h) * P.S_pad + row] = dsum;   // for the dK/dV pass
     }
     const int kv_end = CAUSAL ? min(len, (qblk + 1) * (32 * NW)) : len;
     const int ntiles = (kv_end + 63) >> 6;
@@ -496,7 +488,7 @@ extern "C" int rv_attn_bwd(const void* q, int64_t ld_q, const void* k, int64_t l
                            int HD, int causal, float scale, const void* zeros16, void* stream) {
     if (!q || !k || !v || !o || !dout || !qT || !kT || !doT || !lse || !delta || !dq || !dk || !dv || !zeros16) return RV_ERR_ARG;
     if ((HD != 64 && HD != 128) || (S_pad & 63) || S_pad < S || B <= 0 || H <= 0 || S <= 0) return RV_ERR_ARG;
-    if ((ld_q & 7) || (ld_k & 7) || (ld_v & 7) || (ld_do & 7) || (ld_o & 1) || (ld_dq & 3) || (ld_dk & 3) || (ld_dv & 3)) return RV_ERR_ARG;
+    if ((ld_q & 7) || (ld_k & 7) || (ld_v & 7) || (ld_do & 7) || (ld_o & 7) || (ld_dq & 3) || (ld_dk & 3) || (ld_dv & 3)) return RV_ERR_ARG;
     if (!aligned_ok(q) || !aligned_ok(k) || !aligned_ok(v) || !aligned_ok(dout) || !aligned_ok(qT) || !aligned_ok(kT) || !aligned_ok(doT)) return RV_ERR_ARG;
     AttnParams P = {};
     P.q = (const bf16*)q; P.k = (const bf16*)k; P.v = (const bf16*)v; P.o = (const bf16*)o; P.dout = (const bf16*)dout;
@@ -506,8 +498,6 @@ extern "C" int rv_attn_bwd(const void* q, int64_t ld_q, const void* k, int64_t l
     P.ld_q = ld_q; P.ld_k = ld_k; P.ld_v = ld_v; P.ld_o = ld_o; P.ld_do = ld_do; P.ld_dq = ld_dq; P.ld_dk = ld_dk; P.ld_dv = ld_dv;
     P.B = B; P.H = H; P.S = S; P.S_pad = S_pad; P.scale = scale;
     hipStream_t st = (hipStream_t)stream;
-    const int nw = B * S * H;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((nw * 64 + 255) / 256), dim3(256), 0, st, P, HD);
     // 8 waves per block (2 per SIMD): dQ pass = 256 query rows per block, dK/dV pass = 128 keys per block (16 per wave)
     dim3 grid_dq((S + 255) / 256, H, B), grid_dkv((S + 127) / 128, H, B);
     const int smem_dq = 2 * (2 * 64 * HD * 2 + HD * 128);
