@@ -252,150 +252,99 @@ DEVINL bf16x8 frag_get(const Frag& f) {
 
 #define BAR_LGKM() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-template <bool TA, bool TB, int MODE>
-__global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wid = wave_id(), lane = lane_id();
-    const int wr = wid >> 2, wc = wid & 3;
+// One K-tile step of the 256x256 kernel (4 phases x 16 MFMAs per wave); ph1..ph4 issue this step's LDS-DMA staging.
+template <bool TA, bool TB, class F1, class F2, class F3, class F4>
+DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int brow0, int lane, F1 ph1, F2 ph2, F3 ph3, F4 ph4) {
+    Frag fa[4][2], fb[2][2][2];
+    bf16x8 a[4][2], b[2][2][2];
 
-    const int nwg = P.tiles_m * P.tiles_n;
-    const int kslice = MODE == 2 ? (int)blockIdx.x % P.splits : 0;
-    int pid = xcd_remap(MODE == 2 ? (int)blockIdx.x / P.splits : (int)blockIdx.x, nwg);
-    constexpr int GROUP_M = 4;
-    const int per_group = GROUP_M * P.tiles_n;
-    const int group = pid / per_group;
-    const int first_m = group * GROUP_M;
-    const int gsz = min(P.tiles_m - first_m, GROUP_M);
-    const int tm = first_m + (pid % per_group) % gsz;
-    const int tn = (pid % per_group) / gsz;
-    const int m0 = tm * BM2, n0 = tn * BN2;
+    // ---- phase 1: read A(mh0), B(nh0) and, ahead of time, B(nh1)
+    ph1();
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) frag_issue<TB, true>(fb[0][j][kk], Bt, brow0 + j * 16, kk, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) frag_issue<TA>(fa[i][kk], At, i * 16, kk, lane);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) frag_issue<TB, true>(fb[1][j][kk], Bt, brow0 + 32 + j * 16, kk, lane);
+    constexpr int B1_OPS = TB ? 8 : 4;   // the B(nh1) prefetch stays in flight behind phase 1's MFMAs
+    frag_wait4<TB, B1_OPS>(fb[0][0][0], fb[0][1][0], fb[0][0][1], fb[0][1][1]);
+    frag_wait4<TA, B1_OPS>(fa[0][0], fa[1][0], fa[2][0], fa[3][0]);
+    frag_wait4<TA, B1_OPS>(fa[0][1], fa[1][1], fa[2][1], fa[3][1]);
+    if (TA || TB) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[0][j][kk] = frag_get<TB>(fb[0][j][kk]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i][kk] = frag_get<TA>(fa[i][kk]);
+    }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(b[0][j][kk], a[i][kk], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
 
-    f32x4 acc[8][4];
+    // ---- phase 2: B(nh1) has landed behind phase 1's MFMAs; A(mh1) is read k-step by k-step behind this phase's MFMAs
+    ph2();
+    BAR_LGKM();   // every wave's B reads of tile t are complete -> the B slot of tile t may be restaged
+    frag_wait4<TB>(fb[1][0][0], fb[1][1][0], fb[1][0][1], fb[1][1][1]);
+    if (TB) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // K-tile steps of this block: the whole K (MODE 0), K then K2 (MODE 1), or this block's slice of K (MODE 2)
-    const int nt1 = (P.K + BK - 1) / BK;
-    const int t0 = MODE == 2 ? (int)((long)kslice * nt1 / P.splits) : 0;
-    const int nt = MODE == 2 ? (int)((long)(kslice + 1) * nt1 / P.splits) - t0 : (MODE == 1 ? nt1 + (P.K2 + BK - 1) / BK : nt1);
-    auto stageA = [&](int t, int slot, int h) {
-        char* dst = smem + (slot * 2 + h) * HALF_BYTES;
-        if (MODE == 1 && t >= nt1) stage_half<TA>(P.A2, P.lda2, m0 + h * 128, P.M, (t - nt1) * BK, P.K2, P.zeros, dst, wid, lane);
-        else stage_half<TA>(P.A, P.lda, m0 + h * 128, P.M, (t0 + t) * BK, P.K, P.zeros, dst, wid, lane);
-    };
-    auto stageB = [&](int t, int h) {
-        char* dst = smem + B_RING_OFF + ((t & 1) * 2 + h) * HALF_BYTES;
-        if (MODE == 1 && t >= nt1) stage_half<TB, true>(P.B2, P.ldb2, n0 + h * 128, P.N, (t - nt1) * BK, P.K2, P.zeros, dst, wid, lane);
-        else stage_half<TB, true>(P.B, P.ldb, n0 + h * 128, P.N, (t0 + t) * BK, P.K, P.zeros, dst, wid, lane);
-    };
-
-    // prologue: tiles 0 and 1 (tile 1 stays in flight)
-    stageA(0, 0, 0); stageA(0, 0, 1); stageB(0, 0); stageB(0, 1);
-    if (nt > 1) { stageA(1, 1, 0); stageA(1, 1, 1); stageB(1, 0); stageB(1, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    int aslot = 0;          // A ring slot of tile t (t % 3)
-    for (int t = 0; t < nt; ++t) {
-        const char* At = smem + (aslot * 2 + wr) * HALF_BYTES;
-        const char* Bt = smem + B_RING_OFF + ((t & 1) * 2 + (wc >> 1)) * HALF_BYTES;
-        const int aslot2 = aslot == 0 ? 2 : aslot - 1;   // (t + 2) % 3: the slot tile t-1 just vacated
-        const int brow0 = (wc & 1) * 64;
-        Frag fa[4][2], fb[2][2][2];
-        bf16x8 a[4][2], b[2][2][2];
-
-        // ---- phase 1: read A(mh0), B(nh0) and, ahead of time, B(nh1)
-        if (t + 2 < nt) stageA(t + 2, aslot2, 0);
+        for (int j = 0; j < 2; ++j) b[1][j][kk] = frag_get<TB>(fb[1][j][kk]);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) frag_issue<TB, true>(fb[0][j][kk], Bt, brow0 + j * 16, kk, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) frag_issue<TA>(fa[i][kk], At, i * 16, kk, lane);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) frag_issue<TB, true>(fb[1][j][kk], Bt, brow0 + 32 + j * 16, kk, lane);
-        constexpr int B1_OPS = TB ? 8 : 4;   // the B(nh1) prefetch stays in flight behind phase 1's MFMAs
-        frag_wait4<TB, B1_OPS>(fb[0][0][0], fb[0][1][0], fb[0][0][1], fb[0][1][1]);
-        frag_wait4<TA, B1_OPS>(fa[0][0], fa[1][0], fa[2][0], fa[3][0]);
-        frag_wait4<TA, B1_OPS>(fa[0][1], fa[1][1], fa[2][1], fa[3][1]);
-        if (TA || TB) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[0][j][kk] = frag_get<TB>(fb[0][j][kk]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i][kk] = frag_get<TA>(fa[i][kk]);
-        }
+    for (int kk = 0; kk < 2; ++kk) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(b[0][j][kk], a[i][kk], acc[i][j]);
+            for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma16(b[1][j][kk], a[i][kk], acc[i][2 + j]);
         __builtin_amdgcn_s_setprio(0);
-
-        // ---- phase 2: B(nh1) has landed behind phase 1's MFMAs; A(mh1) is read k-step by k-step behind this phase's MFMAs
-        if (t + 2 < nt) stageA(t + 2, aslot2, 1);
-        BAR_LGKM();   // every wave's B reads of tile t are complete -> the B slot of tile t may be restaged
-        frag_wait4<TB>(fb[1][0][0], fb[1][1][0], fb[1][0][1], fb[1][1][1]);
-        if (TB) __builtin_amdgcn_sched_barrier(0);
+        // a[.][kk] is dead now: fetch A(mh1) for this k-step while the other k-step's MFMAs run
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[1][j][kk] = frag_get<TB>(fb[1][j][kk]);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma16(b[1][j][kk], a[i][kk], acc[i][2 + j]);
-            __builtin_amdgcn_s_setprio(0);
-            // a[.][kk] is dead now: fetch A(mh1) for this k-step while the other k-step's MFMAs run
-#pragma unroll
-            for (int i = 0; i < 4; ++i) frag_issue<TA>(fa[i][kk], At, 64 + i * 16, kk, lane);
-        }
-
-        // ---- phase 3
-        if (t + 2 < nt) stageB(t + 2, 0);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            if (kk == 0) frag_wait4<TA, 8>(fa[0][0], fa[1][0], fa[2][0], fa[3][0]);   // the k-step-1 reads stay in flight
-            else frag_wait4<TA, 0>(fa[0][1], fa[1][1], fa[2][1], fa[3][1]);
-            if (TA) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a[i][kk] = frag_get<TA>(fa[i][kk]);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = mfma16(b[1][j][kk], a[i][kk], acc[4 + i][2 + j]);
-            __builtin_amdgcn_s_setprio(0);
-        }
-
-        // ---- phase 4
-        if (t + 2 < nt) stageB(t + 2, 1);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[4 + i][j] = mfma16(b[0][j][kk], a[i][kk], acc[4 + i][j]);
-        __builtin_amdgcn_s_setprio(0);
-        // tile t+1 (issued during tile t-1) must have landed; the 8 loads of tile t+2 stay in flight
-        if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        aslot = aslot == 2 ? 0 : aslot + 1;
-        BAR_LGKM();   // also: every wave's A reads of tile t are complete -> the A halves of this slot may be restaged
+        for (int i = 0; i < 4; ++i) frag_issue<TA>(fa[i][kk], At, 64 + i * 16, kk, lane);
     }
 
+    // ---- phase 3
+    ph3();
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        if (kk == 0) frag_wait4<TA, 8>(fa[0][0], fa[1][0], fa[2][0], fa[3][0]);   // the k-step-1 reads stay in flight
+        else frag_wait4<TA, 0>(fa[0][1], fa[1][1], fa[2][1], fa[3][1]);
+        if (TA) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i][kk] = frag_get<TA>(fa[i][kk]);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = mfma16(b[1][j][kk], a[i][kk], acc[4 + i][2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+    }
+
+    // ---- phase 4
+    ph4();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[4 + i][j] = mfma16(b[0][j][kk], a[i][kk], acc[4 + i][j]);
+    __builtin_amdgcn_s_setprio(0);
+}
+
+template <int MODE>
+DEVINL void epilogue_256(const f32x4 (&acc)[8][4], const GemmParams& P, int m0, int n0, int wr, int wc, int lane, int kslice) {
     // epilogue: with the interleaved B rows a lane holds, for m = m0 + wr*128 + i*16 + (lane&15), the 8 consecutive columns
     // n = n0 + wc*64 + 32a + 8*(lane>>4) + {0..7}: acc[i][2a][0..3] then acc[i][2a+1][0..3]
     const bool n_vec_ok = (P.N % 8 == 0) && (P.ldc % 8 == 0) && (!P.R || P.ldr % 8 == 0) &&
@@ -469,6 +418,70 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
     }
 }
 
+template <bool TA, bool TB, int MODE>
+__global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wid = wave_id(), lane = lane_id();
+    const int wr = wid >> 2, wc = wid & 3;
+
+    const int nwg = P.tiles_m * P.tiles_n;
+    const int kslice = MODE == 2 ? (int)blockIdx.x % P.splits : 0;
+    int pid = xcd_remap(MODE == 2 ? (int)blockIdx.x / P.splits : (int)blockIdx.x, nwg);
+    constexpr int GROUP_M = 4;
+    const int per_group = GROUP_M * P.tiles_n;
+    const int group = pid / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(P.tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (pid % per_group) % gsz;
+    const int tn = (pid % per_group) / gsz;
+    const int m0 = tm * BM2, n0 = tn * BN2;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // K-tile steps of this block: the whole K (MODE 0), K then K2 (MODE 1), or this block's slice of K (MODE 2)
+    const int nt1 = (P.K + BK - 1) / BK;
+    const int t0 = MODE == 2 ? (int)((long)kslice * nt1 / P.splits) : 0;
+    const int nt = MODE == 2 ? (int)((long)(kslice + 1) * nt1 / P.splits) - t0 : (MODE == 1 ? nt1 + (P.K2 + BK - 1) / BK : nt1);
+    auto stageA = [&](int t, int slot, int h) {
+        char* dst = smem + (slot * 2 + h) * HALF_BYTES;
+        if (MODE == 1 && t >= nt1) stage_half<TA>(P.A2, P.lda2, m0 + h * 128, P.M, (t - nt1) * BK, P.K2, P.zeros, dst, wid, lane);
+        else stage_half<TA>(P.A, P.lda, m0 + h * 128, P.M, (t0 + t) * BK, P.K, P.zeros, dst, wid, lane);
+    };
+    auto stageB = [&](int t, int h) {
+        char* dst = smem + B_RING_OFF + ((t & 1) * 2 + h) * HALF_BYTES;
+        if (MODE == 1 && t >= nt1) stage_half<TB, true>(P.B2, P.ldb2, n0 + h * 128, P.N, (t - nt1) * BK, P.K2, P.zeros, dst, wid, lane);
+        else stage_half<TB, true>(P.B, P.ldb, n0 + h * 128, P.N, (t0 + t) * BK, P.K, P.zeros, dst, wid, lane);
+    };
+
+    // prologue: tiles 0 and 1 (tile 1 stays in flight)
+    stageA(0, 0, 0); stageA(0, 0, 1); stageB(0, 0); stageB(0, 1);
+    if (nt > 1) { stageA(1, 1, 0); stageA(1, 1, 1); stageB(1, 0); stageB(1, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int aslot = 0;          // A ring slot of tile t (t % 3)
+    for (int t = 0; t < nt; ++t) {
+        const char* At = smem + (aslot * 2 + wr) * HALF_BYTES;
+        const char* Bt = smem + B_RING_OFF + ((t & 1) * 2 + (wc >> 1)) * HALF_BYTES;
+        const int aslot2 = aslot == 0 ? 2 : aslot - 1;   // (t + 2) % 3: the slot tile t-1 just vacated
+        const int brow0 = (wc & 1) * 64;
+        ktile_256<TA, TB>(acc, At, Bt, brow0, lane,
+                          [&]() { if (t + 2 < nt) stageA(t + 2, aslot2, 0); }, [&]() { if (t + 2 < nt) stageA(t + 2, aslot2, 1); },
+                          [&]() { if (t + 2 < nt) stageB(t + 2, 0); }, [&]() { if (t + 2 < nt) stageB(t + 2, 1); });
+        // tile t+1 (issued during tile t-1) must have landed; the 8 loads of tile t+2 stay in flight
+        if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        aslot = aslot == 2 ? 0 : aslot + 1;
+        BAR_LGKM();   // also: every wave's A reads of tile t are complete -> the A halves of this slot may be restaged
+    }
+
+    epilogue_256<MODE>(acc, P, m0, n0, wr, wc, lane, kslice);
+}
+
 // C = act(alpha * sum_s ws[s] + bias) + residual  (finishes a split-K GEMM)
 __global__ void splitk_reduce_kernel(GemmParams P) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -488,7 +501,10 @@ __global__ void splitk_reduce_kernel(GemmParams P) {
 }  // namespace
 
 static int g_force_kernel = 0;  // 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel (RV_GEMM_KERNEL or rv_gemm_select_kernel)
-extern "C" int rv_gemm_select_kernel(int which) { g_force_kernel = which; return RV_OK; }
+extern "C" int rv_gemm_select_kernel(int which) {
+    g_force_kernel = which;
+    return RV_OK;
+}
 
 template <bool TA, bool TB, int MODE>
 static void launch256m(const GemmParams& P, hipStream_t st) {
