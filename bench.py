@@ -160,6 +160,8 @@ def main():
     from radvlm_amd.config import GEOMETRIES
     from radvlm_amd.engine import LlavaEngine
     lib.load()
+    if os.environ.get("RV_TAIL_SPLIT") == "0":   # A/B switch for the GEMM tail-round K-split (default on)
+        lib.load().rv_gemm_select_kernel(20)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

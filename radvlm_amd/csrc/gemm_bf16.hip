@@ -30,6 +30,9 @@ struct GemmParams {
     const bf16* A2; const bf16* B2; long lda2, ldb2; int K2;
     // MODE 2 (split-K for outputs with few tiles): block = (tile, slice); raw fp32 partials go to ws[slice][M][N]
     float* ws; int splits;
+    // MODE 3 (tail split): blocks [0, n_full) compute whole tiles; the remaining tiles of the last, partly filled round are
+    // each split over `splits` K-slices (fp32 partial tiles in ws, combined by tail_reduce_kernel)
+    int n_full;
 };
 
 DEVINL float apply_act(float x, int act) {
@@ -425,8 +428,14 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
     const int wr = wid >> 2, wc = wid & 3;
 
     const int nwg = P.tiles_m * P.tiles_n;
-    const int kslice = MODE == 2 ? (int)blockIdx.x % P.splits : 0;
-    int pid = xcd_remap(MODE == 2 ? (int)blockIdx.x / P.splits : (int)blockIdx.x, nwg);
+    int vtile = blockIdx.x, kslice = 0;
+    bool sliced = MODE == 2;
+    if (MODE == 2) { vtile = (int)blockIdx.x / P.splits; kslice = (int)blockIdx.x % P.splits; }
+    if (MODE == 3 && (int)blockIdx.x >= P.n_full) {
+        const int r = (int)blockIdx.x - P.n_full;
+        vtile = P.n_full + r / P.splits; kslice = r % P.splits; sliced = true;
+    }
+    int pid = xcd_remap(vtile, nwg);
     constexpr int GROUP_M = 4;
     const int per_group = GROUP_M * P.tiles_n;
     const int group = pid / per_group;
@@ -444,8 +453,8 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
 
     // K-tile steps of this block: the whole K (MODE 0), K then K2 (MODE 1), or this block's slice of K (MODE 2)
     const int nt1 = (P.K + BK - 1) / BK;
-    const int t0 = MODE == 2 ? (int)((long)kslice * nt1 / P.splits) : 0;
-    const int nt = MODE == 2 ? (int)((long)(kslice + 1) * nt1 / P.splits) - t0 : (MODE == 1 ? nt1 + (P.K2 + BK - 1) / BK : nt1);
+    const int t0 = sliced ? (int)((long)kslice * nt1 / P.splits) : 0;
+    const int nt = sliced ? (int)((long)(kslice + 1) * nt1 / P.splits) - t0 : (MODE == 1 ? nt1 + (P.K2 + BK - 1) / BK : nt1);
     auto stageA = [&](int t, int slot, int h) {
         char* dst = smem + (slot * 2 + h) * HALF_BYTES;
         if (MODE == 1 && t >= nt1) stage_half<TA>(P.A2, P.lda2, m0 + h * 128, P.M, (t - nt1) * BK, P.K2, P.zeros, dst, wid, lane);
@@ -479,7 +488,20 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
         BAR_LGKM();   // also: every wave's A reads of tile t are complete -> the A halves of this slot may be restaged
     }
 
-    epilogue_256<MODE>(acc, P, m0, n0, wr, wc, lane, kslice);
+    if (MODE == 3 && sliced) {
+        // raw fp32 partial tile, tile-local [256][256] layout: slab = (tail tile index) * splits + kslice
+        float* slab = P.ws + ((long)(vtile - P.n_full) * P.splits + kslice) * (BM2 * BN2);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                float* wp = slab + (wr * 128 + i * 16 + (lane & 15)) * BN2 + wc * 64 + 32 * a + 8 * (lane >> 4);
+                *(f32x4*)wp = acc[i][2 * a];
+                *(f32x4*)(wp + 4) = acc[i][2 * a + 1];
+            }
+        return;
+    }
+    epilogue_256<MODE == 3 ? 0 : MODE>(acc, P, m0, n0, wr, wc, lane, kslice);
 }
 
 // C = act(alpha * sum_s ws[s] + bias) + residual  (finishes a split-K GEMM)
@@ -498,10 +520,45 @@ __global__ void splitk_reduce_kernel(GemmParams P) {
     else ((bf16*)P.C)[(long)m * P.ldc + n] = f2bf(s);
 }
 
+// Finishes MODE 3: for every tail tile, C = act(alpha * sum_slices partial + bias) + residual (8 columns per thread).
+__global__ __launch_bounds__(256) void tail_reduce_kernel(GemmParams P) {
+    const int nwg = P.tiles_m * P.tiles_n;
+    const int tt = blockIdx.x >> 5;                       // tail tile index; 32 blocks x 256 threads x 8 columns per tile
+    const int e = ((blockIdx.x & 31) * 256 + threadIdx.x) * 8;
+    const int row = e >> 8, col = e & 255;
+    const int pid = xcd_remap(P.n_full + tt, nwg);
+    constexpr int GROUP_M = 4;
+    const int per_group = GROUP_M * P.tiles_n;
+    const int group = pid / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsz = min(P.tiles_m - first_m, GROUP_M);
+    const int m = (first_m + (pid % per_group) % gsz) * BM2 + row;
+    const int n = ((pid % per_group) / gsz) * BN2 + col;
+    if (m >= P.M || n >= P.N) return;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < P.splits; ++k) {
+        const float* sp = P.ws + ((long)tt * P.splits + k) * (BM2 * BN2) + row * BN2 + col;
+        const f32x4 a = *(const f32x4*)sp, b = *(const f32x4*)(sp + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] += a[r]; v[4 + r] += b[r]; }
+    }
+    const int nv = min(8, P.N - n);
+    for (int r = 0; r < nv; ++r) {
+        float x = v[r] * P.alpha;
+        if (P.bias) x += bf2f(P.bias[n + r]);
+        x = apply_act(x, P.act);
+        if (P.R) x += P.res_f32 ? ((const float*)P.R)[(long)m * P.ldr + n + r] : bf2f(((const bf16*)P.R)[(long)m * P.ldr + n + r]);
+        if (P.out_f32) ((float*)P.C)[(long)m * P.ldc + n + r] = x;
+        else ((bf16*)P.C)[(long)m * P.ldc + n + r] = f2bf(x);
+    }
+}
+
 }  // namespace
 
+static int g_tail_split = 1;   // rv_gemm_select_kernel(20) disables the tail split (A/B), (21) enables
 static int g_force_kernel = 0;  // 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel (RV_GEMM_KERNEL or rv_gemm_select_kernel)
 extern "C" int rv_gemm_select_kernel(int which) {
+    if (which >= 20) { g_tail_split = which - 20; return RV_OK; }
     g_force_kernel = which;
     return RV_OK;
 }
@@ -510,8 +567,10 @@ template <bool TA, bool TB, int MODE>
 static void launch256m(const GemmParams& P, hipStream_t st) {
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute((const void*)gemm_kernel_256<TA, TB, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2); set = true; }
-    const int blocks = P.tiles_m * P.tiles_n * (MODE == 2 ? P.splits : 1);
+    const int nwg = P.tiles_m * P.tiles_n;
+    const int blocks = MODE == 2 ? nwg * P.splits : (MODE == 3 ? P.n_full + (nwg - P.n_full) * P.splits : nwg);
     hipLaunchKernelGGL((gemm_kernel_256<TA, TB, MODE>), dim3(blocks), dim3(512), LDS_BYTES2, st, P);
+    if (MODE == 3) hipLaunchKernelGGL(tail_reduce_kernel, dim3((nwg - P.n_full) * 32), dim3(256), 0, st, P);
     if (MODE == 2) {
         const long total = (long)P.M * P.N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P);
@@ -521,6 +580,7 @@ template <bool TA, bool TB>
 static void launch256(const GemmParams& P, int mode, hipStream_t st) {
     if (mode == 1) launch256m<TA, TB, 1>(P, st);
     else if (mode == 2) launch256m<TA, TB, 2>(P, st);
+    else if (mode == 3) launch256m<TA, TB, 3>(P, st);
     else launch256m<TA, TB, 0>(P, st);
 }
 
@@ -558,6 +618,17 @@ extern "C" int rv_gemm_bf16_ex(const void* A, int64_t lda, const void* B, int64_
         if (sp > nt / 4) sp = nt / 4;
         if (sp > 32) sp = 32;
         if (sp >= 2 && (int64_t)sp * M * N * 4 <= workspace_bytes) { mode = 2; P.splits = sp; }
+    }
+    // tail split: when the last round of 256 CUs is at most half full, its tiles are cut into 2-4 K-slices so that the
+    // round costs 1/2 - 1/4 of a full one (e.g. 1408 tiles: 6 rounds -> 5.5)
+    P.n_full = 0;
+    if (mode == 0 && workspace && g_tail_split && tiles256 > 256) {
+        const int rem = (int)(tiles256 % 256);
+        if (rem > 0 && rem <= 128 && nt >= 32) {
+            int sp = 256 / rem;
+            if (sp > 4) sp = 4;
+            if ((int64_t)rem * sp * BM2 * BN2 * 4 <= workspace_bytes) { mode = 3; P.splits = sp; P.n_full = (int)(tiles256 - rem); }
+        }
     }
     // the 128x128 kernel only exists for the plain NT form
     // tile-shape choice for the plain NT form: whole rounds of 256 CUs (256^2 tiles, 1 block/CU) against double-rounds of

