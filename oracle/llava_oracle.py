@@ -42,10 +42,13 @@ def param_shapes(geo, with_newline=False):
     v, l = geo["vision"], geo["lm"]
     s = {}
     s["model.embed_tokens.weight"] = (l["vocab"], l["d"])
+    kvd = l["d"] // l["heads"] * l.get("kv_heads", l["heads"])   # Qwen2 GQA: k/v project to kv_heads * head_dim
     for i in range(l["layers"]):
         p = f"model.layers.{i}."
-        for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
-            s[p + f"self_attn.{n}.weight"] = (l["d"], l["d"])
+        for n, rows in (("q_proj", l["d"]), ("k_proj", kvd), ("v_proj", kvd), ("o_proj", l["d"])):
+            s[p + f"self_attn.{n}.weight"] = (rows, l["d"])
+            if l.get("qkv_bias") and n != "o_proj":              # HF:models/qwen2/modeling_qwen2.py Qwen2Attention
+                s[p + f"self_attn.{n}.bias"] = (rows,)
         s[p + "mlp.gate_proj.weight"] = (l["ffn"], l["d"])
         s[p + "mlp.up_proj.weight"] = (l["ffn"], l["d"])
         s[p + "mlp.down_proj.weight"] = (l["d"], l["ffn"])
@@ -53,12 +56,17 @@ def param_shapes(geo, with_newline=False):
         s[p + "post_attention_layernorm.weight"] = (l["d"],)
     s["model.norm.weight"] = (l["d"],)
     vp = "model.vision_tower.vision_tower.vision_model."
-    npos = (v["image"] // v["patch"]) ** 2 + 1
-    s[vp + "embeddings.class_embedding"] = (v["d"],)
+    siglip = v.get("kind") == "siglip"
+    npos = (v["image"] // v["patch"]) ** 2 + (0 if siglip else 1)
+    if not siglip:
+        s[vp + "embeddings.class_embedding"] = (v["d"],)
     s[vp + "embeddings.patch_embedding.weight"] = (v["d"], 3, v["patch"], v["patch"])
+    if siglip:   # multimodal_encoder/siglip_encoder.py:148-174: conv with bias, no CLS, no pre-LN
+        s[vp + "embeddings.patch_embedding.bias"] = (v["d"],)
     s[vp + "embeddings.position_embedding.weight"] = (npos, v["d"])
-    s[vp + "pre_layrnorm.weight"] = (v["d"],)
-    s[vp + "pre_layrnorm.bias"] = (v["d"],)
+    if not siglip:
+        s[vp + "pre_layrnorm.weight"] = (v["d"],)
+        s[vp + "pre_layrnorm.bias"] = (v["d"],)
     for i in range(v["layers"]):
         p = vp + f"encoder.layers.{i}."
         for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
@@ -138,30 +146,38 @@ def swiglu_mlp(x, wg, wu, wd):
     return F.linear(F.silu(F.linear(x, wg)) * F.linear(x, wu), wd)
 
 
-def decoder_layer(x, P, pre, heads, lens, cos, sin, eps=1e-5):
-    """LlamaDecoderLayer.forward, modeling_llama.py:852-911 (pre-norm residual block)."""
+def decoder_layer(x, P, pre, heads, lens, cos, sin, eps=1e-5, kv_heads=None):
+    """LlamaDecoderLayer.forward, modeling_llama.py:852-911 (pre-norm residual block).  With kv_heads < heads and
+    q/k/v biases it is the Qwen2 layer LlavaQwenForCausalLM runs (language_model/llava_qwen.py:46-58 ->
+    HF:models/qwen2/modeling_qwen2.py Qwen2DecoderLayer): same block, k/v heads repeated (repeat_kv, modeling_llama.py:201-210)."""
     b, S, d = x.shape
     hd = d // heads
+    kvh = kv_heads or heads
+    bias = lambda n: P.get(pre + f"self_attn.{n}.bias")
     h = rmsnorm(x, P[pre + "input_layernorm.weight"], eps)
-    q = F.linear(h, P[pre + "self_attn.q_proj.weight"]).view(b, S, heads, hd).transpose(1, 2)
-    k = F.linear(h, P[pre + "self_attn.k_proj.weight"]).view(b, S, heads, hd).transpose(1, 2)
-    v = F.linear(h, P[pre + "self_attn.v_proj.weight"]).view(b, S, heads, hd).transpose(1, 2)
+    q = F.linear(h, P[pre + "self_attn.q_proj.weight"], bias("q_proj")).view(b, S, heads, hd).transpose(1, 2)
+    k = F.linear(h, P[pre + "self_attn.k_proj.weight"], bias("k_proj")).view(b, S, kvh, hd).transpose(1, 2)
+    v = F.linear(h, P[pre + "self_attn.v_proj.weight"], bias("v_proj")).view(b, S, kvh, hd).transpose(1, 2)
     q, k = apply_rope(q, k, cos, sin)
+    if kvh != heads:
+        k = k.repeat_interleave(heads // kvh, dim=1)
+        v = v.repeat_interleave(heads // kvh, dim=1)
     a = attention(q, k, v, lens=lens, causal=True).transpose(1, 2).reshape(b, S, d)
     x = x + F.linear(a, P[pre + "self_attn.o_proj.weight"])
     h = rmsnorm(x, P[pre + "post_attention_layernorm.weight"], eps)
     return x + swiglu_mlp(h, P[pre + "mlp.gate_proj.weight"], P[pre + "mlp.up_proj.weight"], P[pre + "mlp.down_proj.weight"])
 
 
-def llama_forward(P, geo, embeds, lens, eps=1e-5):
+def llama_forward(P, geo, embeds, lens, eps=None):
     """LlamaModel.forward + lm_head, modeling_llama.py:1083-1185, 1323; position_ids = arange(S) for every row
     (the reference discards the spliced position_ids in training, llava_arch.py:534-545)."""
     l = geo["lm"]
     b, S, d = embeds.shape
-    cos, sin = rope_cos_sin(S, d // l["heads"], dtype=embeds.dtype)
+    eps = eps if eps is not None else l.get("rms_eps", 1e-5)
+    cos, sin = rope_cos_sin(S, d // l["heads"], theta=l.get("rope_theta", 10000.0), dtype=embeds.dtype)
     x = embeds
     for i in range(l["layers"]):
-        x = decoder_layer(x, P, f"model.layers.{i}.", l["heads"], lens, cos, sin, eps)
+        x = decoder_layer(x, P, f"model.layers.{i}.", l["heads"], lens, cos, sin, eps, l.get("kv_heads"))
     x = rmsnorm(x, P["model.norm.weight"], eps)
     return F.linear(x, P["lm_head.weight"])
 
@@ -211,8 +227,38 @@ def clip_vision_hidden(P, geo, pixels, select_layer=-2):
     return x
 
 
+def siglip_vision_hidden(P, geo, pixels):
+    """SigLipVisionTower.forward, multimodal_encoder/siglip_encoder.py:576-590: hidden_states[-1] of the encoder whose
+    LAST layer was deleted at load (:570), head = Identity (:571), post_layernorm not applied to hidden_states.
+
+    Embeddings :148-174 (conv WITH bias, 'valid' padding, learned positions, no CLS / pre-LN); encoder layer :259-306
+    (pre-LN, MHSA :177-240 with scale head_dim^-0.5 and biases, MLP :243-256 with gelu_pytorch_tanh); eps 1e-6 (:83)."""
+    v = geo["vision"]
+    vp = "model.vision_tower.vision_tower.vision_model."
+    n = pixels.shape[0]
+    x = F.conv2d(pixels, P[vp + "embeddings.patch_embedding.weight"], P[vp + "embeddings.patch_embedding.bias"], stride=v["patch"])
+    x = x.flatten(2).transpose(1, 2) + P[vp + "embeddings.position_embedding.weight"][None]
+    N, d, H = x.shape[1], v["d"], v["heads"]
+    hd = d // H
+    for i in range(v["layers"] - 1):
+        p = vp + f"encoder.layers.{i}."
+        h = F.layer_norm(x, (d,), P[p + "layer_norm1.weight"], P[p + "layer_norm1.bias"], 1e-6)
+        q = F.linear(h, P[p + "self_attn.q_proj.weight"], P[p + "self_attn.q_proj.bias"]).view(n, N, H, hd).transpose(1, 2)
+        k = F.linear(h, P[p + "self_attn.k_proj.weight"], P[p + "self_attn.k_proj.bias"]).view(n, N, H, hd).transpose(1, 2)
+        vv = F.linear(h, P[p + "self_attn.v_proj.weight"], P[p + "self_attn.v_proj.bias"]).view(n, N, H, hd).transpose(1, 2)
+        a = attention(q, k, vv, lens=None, causal=False).transpose(1, 2).reshape(n, N, d)
+        x = x + F.linear(a, P[p + "self_attn.out_proj.weight"], P[p + "self_attn.out_proj.bias"])
+        h = F.layer_norm(x, (d,), P[p + "layer_norm2.weight"], P[p + "layer_norm2.bias"], 1e-6)
+        h = F.gelu(F.linear(h, P[p + "mlp.fc1.weight"], P[p + "mlp.fc1.bias"]), approximate="tanh")
+        x = x + F.linear(h, P[p + "mlp.fc2.weight"], P[p + "mlp.fc2.bias"])
+    return x
+
+
 def vision_tower(P, geo, pixels):
-    """CLIPVisionTower.forward + feature_select, multimodal_encoder/clip_encoder.py:46-79 (layer -2, drop CLS)."""
+    """CLIPVisionTower.forward + feature_select, multimodal_encoder/clip_encoder.py:46-79 (layer -2, drop CLS); or the
+    SigLIP tower (all 729 patch tokens)."""
+    if geo["vision"].get("kind") == "siglip":
+        return siglip_vision_hidden(P, geo, pixels)
     return clip_vision_hidden(P, geo, pixels, -2)[:, 1:]
 
 
@@ -295,6 +341,12 @@ def merge_image_features(feats_per_sample, cfg, P, image_sizes, side):
             if "unpad" in mt:
                 rest = rest.permute(4, 0, 2, 1, 3).contiguous().flatten(1, 2).flatten(2, 3)
                 rest = unpad_image(rest, image_sizes[idx])
+                mx = re.match(r"anyres_max_(\d+)", cfg.get("image_aspect_ratio", ""))
+                if mx:   # llava_arch.py:381-392: bilinear down-sampling once the grid exceeds max_num_patches tiles
+                    c, hh, ww = rest.shape
+                    times = math.sqrt(hh * ww / (int(mx.group(1)) * side ** 2))
+                    if times > 1.1:
+                        rest = F.interpolate(rest[None], [int(hh // times), int(ww // times)], mode="bilinear")[0]
                 nl = P["model.image_newline"][:, None, None].expand(*rest.shape[:-1], 1)
                 rest = torch.cat((rest, nl), dim=-1).flatten(1, 2).transpose(0, 1)
             else:

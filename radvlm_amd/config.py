@@ -20,6 +20,20 @@ GEOMETRIES = {
         "vision": dict(d=1024, heads=16, ffn=4096, layers=24, image=336, patch=14),
         "lm": dict(d=4096, heads=32, ffn=11008, layers=32, vocab=32000),
     },
+    # the configuration RadVLM really trains (finetune_radio_7b.sh:21-60) = LLaVA-OneVision
+    # Qwen2-7B decoder (GQA 28/4 heads, q/k/v bias, rope theta 1e6) + SigLIP-so400m-patch14-384 tower (729 tokens,
+    # head_dim 72, gelu_tanh MLP, last layer dropped: siglip_encoder.py:538-590)
+    "llava_ov_qwen2_7b": {
+        "vision": dict(kind="siglip", d=1152, heads=16, ffn=4304, layers=27, image=384, patch=14),
+        "lm": dict(d=3584, heads=28, kv_heads=4, ffn=18944, layers=28, vocab=152064, qkv_bias=True, rope_theta=1e6,
+                   rms_eps=1e-6),
+    },
+    # toy version of the above for golden fixtures: 27x27 patches (the reference asserts 729 tokens,
+    # siglip_encoder.py:581/586), head_dim 24 (exercises the head padding), ffn 200 (K tail), GQA 4/2
+    "toy_qwen": {
+        "vision": dict(kind="siglip", d=96, heads=4, ffn=200, layers=3, image=54, patch=2),
+        "lm": dict(d=256, heads=4, kv_heads=2, ffn=448, layers=2, vocab=1000, qkv_bias=True, rope_theta=1e6, rms_eps=1e-6),
+    },
     # BASELINE.json configs[4]: LLaVA-1.5-13B
     "llava15_13b": {
         "vision": dict(d=1024, heads=16, ffn=4096, layers=24, image=336, patch=14),

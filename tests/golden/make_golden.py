@@ -104,10 +104,73 @@ def make_batch(geo, spec, seed_img=1, seed_ids=2, tiles=None):
     return ids, labels, mask, images, modalities
 
 
+def build_reference_qwen_model(mods, geo, seed=0, merge_type="flat", aspect="square", pinpoints=None):
+    """LlavaQwenForCausalLM (language_model/llava_qwen.py:46-58) over a SigLipVisionTower (siglip_encoder.py:538-590).
+
+    build_vision_tower only reaches SigLipVisionTower for a hub name (builder.py:16-22) and load_model() would fetch it,
+    so the tower is created with delay_load and load_model's three steps (:568-572: build SigLipVisionModel, delete the
+    last encoder layer, head = Identity) are performed here on a randomly initialised toy-sized SigLipVisionModel."""
+    import importlib
+    lq = importlib.import_module("llava.model.language_model.llava_qwen")
+    se = importlib.import_module("llava.model.multimodal_encoder.siglip_encoder")
+    v, l = geo["vision"], geo["lm"]
+
+    class _Cfg(lq.LlavaQwenConfig):
+        """transformers-5 skew: there ``rope_scaling`` aliases ``rope_parameters`` (which also holds theta), so the
+        reference's 4.x-era ``config.rope_scaling = None`` (llava_qwen.py:53) would delete the rope setup; ignore it
+        (in 4.x it is a no-op for a config without scaling)."""
+
+        def __setattr__(self, k, val):
+            if k == "rope_scaling" and val is None:
+                return
+            super().__setattr__(k, val)
+
+    cfg = _Cfg(hidden_size=l["d"], intermediate_size=l["ffn"], num_hidden_layers=l["layers"],
+                             num_attention_heads=l["heads"], num_key_value_heads=l["kv_heads"], vocab_size=l["vocab"],
+                             rms_norm_eps=l["rms_eps"], max_position_embeddings=8192, rope_theta=l["rope_theta"],
+                             tie_word_embeddings=False, attn_implementation="eager", use_sliding_window=False)
+    cfg.mm_vision_tower = "toy/siglip-27x27"      # not a path: builder.py routes the name to SigLipVisionTower
+    cfg.delay_load = True
+    cfg.mm_projector_type = "mlp2x_gelu"
+    cfg.mm_hidden_size = v["d"]
+    cfg.mm_vision_select_layer = -2
+    cfg.mm_vision_select_feature = "patch"
+    cfg.mm_patch_merge_type = merge_type
+    cfg.image_aspect_ratio = aspect
+    if pinpoints is not None:
+        cfg.image_grid_pinpoints = pinpoints
+    cfg.use_cache = False
+    model = lq.LlavaQwenForCausalLM(cfg)
+    tower = model.get_model().get_vision_tower()
+    assert isinstance(tower, se.SigLipVisionTower) and not tower.is_loaded
+    scfg = se.SigLipVisionConfig(hidden_size=v["d"], intermediate_size=v["ffn"], num_hidden_layers=v["layers"],
+                                 num_attention_heads=v["heads"], image_size=v["image"], patch_size=v["patch"])
+    scfg._attn_implementation = "eager"
+    tower.config = scfg
+    tower.vision_tower = se.SigLipVisionModel(scfg)
+    del tower.vision_tower.vision_model.encoder.layers[-1:]
+    tower.vision_tower.vision_model.head = torch.nn.Identity()
+    tower.vision_tower.requires_grad_(False)
+    tower.is_loaded = True
+    model = model.float()
+    sd = model.state_dict()
+    new = {}
+    for k, t in sd.items():
+        ck = canonical_name(k)
+        kind, std = init_std_for(ck, l["d"])
+        w = prng.normal(seed, prng.name_tag(ck), tuple(t.shape), std)
+        if kind == "norm_weight":
+            w = 1.0 + w
+        new[k] = torch.from_numpy(w).to(t.dtype) if t.dtype.is_floating_point else t
+    model.load_state_dict(new)
+    model.train()
+    return model
+
+
 def run_e2e(mods, geo_name, spec, out_name, grads_full=(), merge_type="flat", aspect="square", pinpoints=None,
-            tiles=None, image_sizes=None, unfreeze_tower=False):
+            tiles=None, image_sizes=None, unfreeze_tower=False, builder=None, slices=False):
     geo = GEOMETRIES[geo_name]
-    model = build_reference_model(mods, geo, merge_type=merge_type, aspect=aspect, pinpoints=pinpoints)
+    model = (builder or build_reference_model)(mods, geo, merge_type=merge_type, aspect=aspect, pinpoints=pinpoints)
     if unfreeze_tower:  # mm_tunable_parts contains mm_vision_tower (train/train.py:1658-1661)
         model.get_model().get_vision_tower().vision_tower.requires_grad_(True)
     ids, labels, mask, images, modalities = make_batch(geo, spec, tiles=tiles)
@@ -133,7 +196,7 @@ def run_e2e(mods, geo_name, spec, out_name, grads_full=(), merge_type="flat", as
         res[f"image{i}"] = im
     logits = out.logits.detach().numpy().astype(np.float32)
     emb = embeds.numpy()
-    if logits.size <= 2_000_000:
+    if logits.size <= 2_000_000 and not slices:
         res["logits"] = logits
         res["inputs_embeds"] = emb
         res["image_features"] = feats.numpy()
@@ -302,5 +365,23 @@ if __name__ == "__main__":
                             vp + "embeddings.class_embedding", vp + "encoder.layers.0.self_attn.q_proj.weight",
                             vp + "encoder.layers.1.mlp.fc1.bias", vp + "encoder.layers.0.layer_norm1.weight",
                             vp + "pre_layrnorm.bias", "model.mm_projector.0.weight"))
+    if "qwen" in which:
+        vp = "model.vision_tower.vision_tower.vision_model."
+        # flat merge, frozen tower: Qwen2 decoder (GQA 4/2, q/k/v bias, theta 1e6) over 729 SigLIP tokens per image
+        run_e2e(mods, "toy_qwen", [(20, 5, 8), (12, 3, 4), (9, None, 2)], "toy_qwen_e2e", builder=build_reference_qwen_model,
+                slices=True, grads_full=("model.layers.0.self_attn.k_proj.weight", "model.layers.1.self_attn.v_proj.bias",
+                                         "model.layers.0.self_attn.q_proj.bias", "model.mm_projector.0.weight", "model.norm.weight"))
+        # anyres_max_2 + spatial_unpad with the tower tunable (the RadVLM recipe, finetune_radio_7b.sh: anyres_max_9,
+        # mm_tunable_parts incl. mm_vision_tower): 2x2 grid -> 54x54 features -> bilinear to 38x38 (times = 1.41 > 1.1),
+        # and a 2x1 grid that stays below the limit (no interpolation)
+        pin = [[54, 108], [108, 54], [108, 108]]
+        sizes = [[100, 100], [100, 40]]
+        tiles = [1 + int(np.prod(mods["mm_utils"].get_anyres_image_grid_shape(sz, pin, 54))) for sz in sizes]
+        run_e2e(mods, "toy_qwen", [(14, 4, 6), (10, 2, 3)], "toy_qwen_anyres_max_e2e", merge_type="spatial_unpad",
+                aspect="anyres_max_2", pinpoints=pin, tiles=tiles, image_sizes=sizes, unfreeze_tower=True,
+                builder=build_reference_qwen_model, slices=True,
+                grads_full=("model.image_newline", vp + "embeddings.patch_embedding.bias",
+                            vp + "encoder.layers.0.self_attn.q_proj.bias", vp + "encoder.layers.1.mlp.fc1.bias",
+                            vp + "embeddings.position_embedding.weight"))
     if "cfg1" in which:
         run_e2e(mods, "config1", [(48, 35, 40)], "config1_e2e")

@@ -110,7 +110,7 @@ def _run_e2e(golden_dir, name, with_newline=False, tower_grads=False):
             v.requires_grad_(True)
     nimg = len([k for k in g.files if k.startswith("image") and k[5:].isdigit()])
     images = [torch.from_numpy(g[f"image{i}"]) for i in range(nimg)]
-    cfg = {"mm_patch_merge_type": meta["merge_type"]}
+    cfg = {"mm_patch_merge_type": meta["merge_type"], "image_aspect_ratio": meta.get("aspect", "square")}
     if meta["pinpoints"]:
         cfg["image_grid_pinpoints"] = meta["pinpoints"]
     loss, logits, aux = O.llava_forward(P, geo, torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"]),
@@ -161,6 +161,32 @@ def test_e2e_toy_tower_unfrozen(golden_dir):
     for k in g.files:
         if k.startswith("grad::"):
             assert _maxrel(P[k[6:]].grad, g[k]) < 1e-4, k
+
+
+def _check_slices(g, P, logits, aux):
+    lg = logits.detach().numpy()
+    assert _maxrel(lg[:, ::7, ::997], g["logits_slice"]) < 1e-4
+    assert abs(np.abs(lg).max() - float(g["logits_absmax"].max())) < 1e-4
+    assert _maxrel(lg.sum(-1), g["logits_rowsum"]) < 1e-4
+    assert _maxrel(aux["inputs_embeds"].detach()[:, :, ::37], g["inputs_embeds_slice"]) < 1e-5
+    assert _maxrel(aux["image_features"].detach()[:, :, ::37], g["image_features_slice"]) < 1e-5
+    for k in g.files:
+        if k.startswith("grad::"):
+            assert _maxrel(P[k[6:]].grad, g[k]) < 1e-4, k
+
+
+def test_e2e_toy_qwen_siglip(golden_dir):
+    """LlavaQwenForCausalLM (GQA 4/2 heads, q/k/v bias, theta 1e6) over the SigLIP tower (729 tokens)."""
+    g, meta, P, loss, logits, aux = _run_e2e(golden_dir, "toy_qwen_e2e")
+    _check_common(g, meta, P, loss, logits, aux)
+    _check_slices(g, P, logits, aux)
+
+
+def test_e2e_toy_qwen_anyres_max(golden_dir):
+    """anyres_max_2 + spatial_unpad (bilinear down-sampling of the unpadded grid, llava_arch.py:381-392), tower tunable."""
+    g, meta, P, loss, logits, aux = _run_e2e(golden_dir, "toy_qwen_anyres_max_e2e", with_newline=True, tower_grads=True)
+    _check_common(g, meta, P, loss, logits, aux)
+    _check_slices(g, P, logits, aux)
 
 
 @pytest.mark.slow
