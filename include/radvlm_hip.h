@@ -20,6 +20,7 @@ extern "C" {
 #define RV_ACT_NONE 0
 #define RV_ACT_QUICK_GELU 1 /* x*sigmoid(1.702x): HF:activations.py QuickGELUActivation (CLIP MLP) */
 #define RV_ACT_GELU 2       /* erf GELU: torch.nn.GELU in multimodal_projector/builder.py:44 */
+#define RV_ACT_GELU_TANH 3  /* gelu_pytorch_tanh: SigLipMLP, multimodal_encoder/siglip_encoder.py:83,:243-256 */
 
 /* Library version / build arch string ("gfx950"). */
 const char* rv_version(void);
@@ -87,6 +88,10 @@ int rv_layernorm_bwd(const void* dy, const void* x, const void* w, const float* 
 int rv_quick_gelu_fwd(const void* x, void* y, int64_t n, void* stream);
 int rv_quick_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);
 
+/* SigLIP MLP activation 0.5x(1+tanh(sqrt(2/pi)(x+0.044715x^3))) (siglip_encoder.py:83 hidden_act) and its derivative. */
+int rv_gelu_tanh_fwd(const void* x, void* y, int64_t n, void* stream);
+int rv_gelu_tanh_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);
+
 /* out[c] (+)= sum_r in[r, c]  (fp32 partial rows -> bf16 vector). */
 int rv_colsum_f32(const float* in, int rows, int cols, void* out_bf16, int accumulate, void* stream);
 /* partial[blk, c] = sum over the block's rows of x[r, c]  (bf16 [rows, cols] with stride ld -> fp32 [nblk, cols]);
@@ -115,6 +120,18 @@ int rv_attn_bwd(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const 
                 const float* lse, float* delta, void* dq, int64_t ld_dq, void* dk, int64_t ld_dk, void* dv,
                 int64_t ld_dv, const int32_t* lens, int B, int H, int S, int S_pad, int hd, int causal, float scale,
                 const void* zeros16, void* stream);
+
+/* Grouped-query form (Qwen2: language_model/llava_qwen.py:46-58 -> HF Qwen2Attention with num_key_value_heads < heads;
+ * repeat_kv modeling_llama.py:201-210): k / v / kT / vT / dk / dv hold H_kv heads, query head h uses key/value head
+ * h / (H / H_kv); the dK/dV pass sums the group's query heads in registers (no expanded copies).  H % H_kv == 0. */
+int rv_attn_fwd_gqa(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* vT, void* out, int64_t ld_o,
+                    float* lse, const int32_t* lens, int B, int H, int H_kv, int S, int S_pad, int hd, int causal,
+                    float scale, const void* zeros16, void* stream);
+int rv_attn_bwd_gqa(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v, const void* o,
+                    int64_t ld_o, const void* dout, int64_t ld_do, const void* qT, const void* kT, const void* doT,
+                    const float* lse, float* delta, void* dq, int64_t ld_dq, void* dk, int64_t ld_dk, void* dv,
+                    int64_t ld_dv, const int32_t* lens, int B, int H, int H_kv, int S, int S_pad, int hd, int causal,
+                    float scale, const void* zeros16, void* stream);
 
 /* ---- MLP activations ------------------------------------------------------------------------------------------------
  * LlamaMLP (modeling_llama.py:226): act[r, f] = silu(gu[r, f]) * gu[r, F + f]   (gu = fused gate|up output). */
@@ -146,11 +163,21 @@ int rv_gather_rows(void* dst, int64_t ld_dst, const void* table_a, int64_t ld_a,
 int rv_segment_sum_rows(const void* src, int64_t ld_src, const int32_t* seg_off, const int32_t* pos,
                         const int32_t* out_row, int nseg, void* out, int64_t ld_out, int d, void* stream);
 
+/* Weighted form: out[out_row[s]] = sum_j w[j] * src[pos[j]].  Forward and adjoint of the anyres_max bilinear
+ * down-sampling nn.functional.interpolate(mode="bilinear") at llava_arch.py:381-392 (4 taps per output row; the
+ * adjoint's CSR is the transposed tap list, built on the host), deterministic (no atomics). */
+int rv_weighted_segment_sum_rows(const void* src, int64_t ld_src, const int32_t* seg_off, const int32_t* pos,
+                                 const float* w, const int32_t* out_row, int nseg, void* out, int64_t ld_out, int d,
+                                 void* stream);
+
 /* ---- CLIP embeddings -----------------------------------------------------------------------------------------------
  * HF:modeling_clip.py:202-218: patches of pix [n,3,H,W] (bf16) -> rows [n*gh*gw, Kp], k = c*p*p + i*p + j (zero
  * padded to Kp); then out[n, 0] = cls + pos[0], out[n, 1+i] = patch_out[n, i] + pos[1+i]. */
 int rv_im2col_patches(const void* pix, void* out, int n, int H, int W, int p, int Kp, void* stream);
 int rv_clip_embed(const void* patch_out, const void* cls, const void* pos, void* out, int n, int P, int d, void* stream);
+/* SigLipVisionEmbeddings (siglip_encoder.py:169-174): x[n, i] += pos[i] in place (no class token; the conv bias rides the
+ * patch GEMM).  rv_im2col_patches accepts H, W that are not multiples of p ('valid' conv: trailing pixels unused). */
+int rv_add_pos_rows(void* x, const void* pos, int n, int P, int d, void* stream);
 
 /* ---- optimizer / misc ----------------------------------------------------------------------------------------------
  * torch.optim.AdamW step (optim="adamw_torch", train/train.py:140) on a flat slice: fp32 master/m/v, bf16 params and

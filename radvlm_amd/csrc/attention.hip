@@ -26,6 +26,7 @@ struct AttnParams {
     const bf16* zeros;
     long ld_q, ld_k, ld_v, ld_o, ld_do, ld_dq, ld_dk, ld_dv;
     int B, H, S, S_pad;
+    int Hkv, nrep;   // grouped-query attention: query head h reads key/value head h / nrep (repeat_kv, modeling_llama.py:201-210)
     float scale;
 };
 
@@ -85,8 +86,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
     }
     const int kv_end = CAUSAL ? min(len, qblk * 128 + 128) : len;
     const int ntiles = (kv_end + 63) >> 6;
-    const bf16* kbase = P.k + (long)b * S * P.ld_k + h * HD;
-    const bf16* vtbase = P.vT + (long)(b * P.H + h) * HD * P.S_pad;
+    const int hk = h / P.nrep;
+    const bf16* kbase = P.k + (long)b * S * P.ld_k + hk * HD;
+    const bf16* vtbase = P.vT + (long)(b * P.Hkv + hk) * HD * P.S_pad;
 
     float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
     f32x4 o[2][DB];
@@ -227,9 +229,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dq_kernel(AttnParams
     }
     const int kv_end = CAUSAL ? min(len, (qblk + 1) * (32 * NW)) : len;
     const int ntiles = (kv_end + 63) >> 6;
-    const bf16* kbase = P.k + (long)b * S * P.ld_k + h * HD;
-    const bf16* vbase = P.v + (long)b * S * P.ld_v + h * HD;
-    const bf16* ktbase = P.kT + (long)(b * P.H + h) * HD * P.S_pad;
+    const int hk = h / P.nrep;
+    const bf16* kbase = P.k + (long)b * S * P.ld_k + hk * HD;
+    const bf16* vbase = P.v + (long)b * S * P.ld_v + hk * HD;
+    const bf16* ktbase = P.kT + (long)(b * P.Hkv + hk) * HD * P.S_pad;
 
     f32x4 dq[2][DB];
 #pragma unroll
@@ -338,12 +341,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dkv_kernel(AttnParam
     const int q_end = len;  // query rows >= len carry zero dO
     const int t0 = CAUSAL ? (kblk * KPB) >> 6 : 0;
     const int t1 = (q_end + 63) >> 6;
-    const bf16* qbase = P.q + (long)b * S * P.ld_q + h * HD;
-    const bf16* dobase = P.dout + (long)b * S * P.ld_do + h * HD;
-    const bf16* qtbase = P.qT + (long)(b * P.H + h) * HD * P.S_pad;
-    const bf16* dotbase = P.doT + (long)(b * P.H + h) * HD * P.S_pad;
-    const float* lsebase = P.lse + (long)(b * P.H + h) * P.S_pad;
-    const float* dlbase = P.delta + (long)(b * P.H + h) * P.S_pad;
+    // blockIdx.y is the KEY/VALUE head; its nrep query heads are walked by one flattened (head, query tile) loop so that
+    // dK/dV accumulate in registers across the group and the double-buffered prefetch runs across head boundaries
+    const int nt = max(t1 - t0, 0);
+    const int n_it = nt * P.nrep;
 
     f32x4 dv[DB][NKB], dk[DB][NKB];
 #pragma unroll
@@ -351,8 +352,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dkv_kernel(AttnParam
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) { dv[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-    auto stage = [&](int t, char* dst) {
-        const int qt0 = t * 64;
+    auto stage = [&](int it, char* dst) {
+        const int hq = h * P.nrep + it / nt;
+        const int qt0 = (t0 + it % nt) * 64;
+        const bf16* qbase = P.q + (long)b * S * P.ld_q + hq * HD;
+        const bf16* dobase = P.dout + (long)b * S * P.ld_do + hq * HD;
+        const bf16* qtbase = P.qT + (long)(b * P.H + hq) * HD * P.S_pad;
+        const bf16* dotbase = P.doT + (long)(b * P.H + hq) * HD * P.S_pad;
+        const float* lsebase = P.lse + (long)(b * P.H + hq) * P.S_pad;
+        const float* dlbase = P.delta + (long)(b * P.H + hq) * P.S_pad;
         stage_rows<KROW, 64, NW>(qbase + (long)qt0 * P.ld_q, P.ld_q, S - qt0, P.zeros, dst, wid, lane);
         stage_rows<KROW, 64, NW>(dobase + (long)qt0 * P.ld_do, P.ld_do, S - qt0, P.zeros, dst + NAT_BYTES, wid, lane);
         stage_rows<128, HD, NW>(qtbase + qt0, P.S_pad, HD, P.zeros, dst + 2 * NAT_BYTES, wid, lane);
@@ -364,17 +372,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dkv_kernel(AttnParam
             glds16(g, dst + 2 * NAT_BYTES + 2 * T_BYTES);
         }
     };
-    if (t0 < t1) stage(t0, smem);
+    if (n_it > 0) stage(0, smem);
 
-    for (int t = t0; t < t1; ++t) {
+    for (int it = 0; it < n_it; ++it) {
+        const int t = t0 + it % nt;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const char* Qt = smem + ((t - t0) & 1) * STAGE;
+        const char* Qt = smem + (it & 1) * STAGE;
         const char* dOt = Qt + NAT_BYTES;
         const char* QTt = Qt + 2 * NAT_BYTES;
         const char* dOTt = QTt + T_BYTES;
         const char* LSt = dOTt + T_BYTES;   // [64 lse | 64 delta] fp32
-        if (t + 1 < t1) stage(t + 1, smem + ((t + 1 - t0) & 1) * STAGE);
+        if (it + 1 < n_it) stage(it + 1, smem + ((it + 1) & 1) * STAGE);
         const int qt0 = t * 64;
         if (CAUSAL && qt0 + 63 < k0) continue;  // every query of this tile precedes this wave's keys
 
@@ -458,16 +467,16 @@ bool aligned_ok(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
 
-extern "C" int rv_attn_fwd(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* vT, void* out,
-                           int64_t ld_o, float* lse, const int32_t* lens, int B, int H, int S, int S_pad, int HD,
-                           int causal, float scale, const void* zeros16, void* stream) {
-    if (!q || !k || !vT || !out || !zeros16 || B <= 0 || H <= 0 || S <= 0) return RV_ERR_ARG;
+extern "C" int rv_attn_fwd_gqa(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* vT, void* out,
+                               int64_t ld_o, float* lse, const int32_t* lens, int B, int H, int H_kv, int S, int S_pad, int HD,
+                               int causal, float scale, const void* zeros16, void* stream) {
+    if (!q || !k || !vT || !out || !zeros16 || B <= 0 || H <= 0 || S <= 0 || H_kv <= 0 || H % H_kv) return RV_ERR_ARG;
     if ((HD != 64 && HD != 128) || (S_pad & 63) || S_pad < S) return RV_ERR_ARG;
     if ((ld_q & 7) || (ld_k & 7) || (ld_o & 3) || !aligned_ok(q) || !aligned_ok(k) || !aligned_ok(vT)) return RV_ERR_ARG;
     AttnParams P = {};
     P.q = (const bf16*)q; P.k = (const bf16*)k; P.vT = (const bf16*)vT; P.out = (bf16*)out; P.lse = lse; P.lens = lens;
     P.zeros = (const bf16*)zeros16; P.ld_q = ld_q; P.ld_k = ld_k; P.ld_o = ld_o;
-    P.B = B; P.H = H; P.S = S; P.S_pad = S_pad; P.scale = scale;
+    P.B = B; P.H = H; P.S = S; P.S_pad = S_pad; P.scale = scale; P.Hkv = H_kv; P.nrep = H / H_kv;
     dim3 grid((S + 127) / 128, H, B);
     const int smem = 2 * (64 * HD * 2 + HD * 128);
 #define LAUNCH_FWD(HD_, C_)                                                                             \
@@ -481,12 +490,19 @@ extern "C" int rv_attn_fwd(const void* q, int64_t ld_q, const void* k, int64_t l
     return rv_check_launch();
 }
 
-extern "C" int rv_attn_bwd(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v,
-                           const void* o, int64_t ld_o, const void* dout, int64_t ld_do, const void* qT, const void* kT,
-                           const void* doT, const float* lse, float* delta, void* dq, int64_t ld_dq, void* dk,
-                           int64_t ld_dk, void* dv, int64_t ld_dv, const int32_t* lens, int B, int H, int S, int S_pad,
-                           int HD, int causal, float scale, const void* zeros16, void* stream) {
+extern "C" int rv_attn_fwd(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* vT, void* out,
+                           int64_t ld_o, float* lse, const int32_t* lens, int B, int H, int S, int S_pad, int HD,
+                           int causal, float scale, const void* zeros16, void* stream) {
+    return rv_attn_fwd_gqa(q, ld_q, k, ld_k, vT, out, ld_o, lse, lens, B, H, H, S, S_pad, HD, causal, scale, zeros16, stream);
+}
+
+extern "C" int rv_attn_bwd_gqa(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v,
+                               const void* o, int64_t ld_o, const void* dout, int64_t ld_do, const void* qT, const void* kT,
+                               const void* doT, const float* lse, float* delta, void* dq, int64_t ld_dq, void* dk,
+                               int64_t ld_dk, void* dv, int64_t ld_dv, const int32_t* lens, int B, int H, int H_kv, int S,
+                               int S_pad, int HD, int causal, float scale, const void* zeros16, void* stream) {
     if (!q || !k || !v || !o || !dout || !qT || !kT || !doT || !lse || !delta || !dq || !dk || !dv || !zeros16) return RV_ERR_ARG;
+    if (H_kv <= 0 || H <= 0 || H % H_kv) return RV_ERR_ARG;
     if ((HD != 64 && HD != 128) || (S_pad & 63) || S_pad < S || B <= 0 || H <= 0 || S <= 0) return RV_ERR_ARG;
     if ((ld_q & 7) || (ld_k & 7) || (ld_v & 7) || (ld_do & 7) || (ld_o & 7) || (ld_dq & 3) || (ld_dk & 3) || (ld_dv & 3)) return RV_ERR_ARG;
     if (!aligned_ok(q) || !aligned_ok(k) || !aligned_ok(v) || !aligned_ok(dout) || !aligned_ok(qT) || !aligned_ok(kT) || !aligned_ok(doT)) return RV_ERR_ARG;
@@ -496,10 +512,11 @@ extern "C" int rv_attn_bwd(const void* q, int64_t ld_q, const void* k, int64_t l
     P.dq = (bf16*)dq; P.dk = (bf16*)dk; P.dv = (bf16*)dv; P.lse = (float*)lse; P.delta = delta; P.lens = lens;
     P.zeros = (const bf16*)zeros16;
     P.ld_q = ld_q; P.ld_k = ld_k; P.ld_v = ld_v; P.ld_o = ld_o; P.ld_do = ld_do; P.ld_dq = ld_dq; P.ld_dk = ld_dk; P.ld_dv = ld_dv;
-    P.B = B; P.H = H; P.S = S; P.S_pad = S_pad; P.scale = scale;
+    P.B = B; P.H = H; P.S = S; P.S_pad = S_pad; P.scale = scale; P.Hkv = H_kv; P.nrep = H / H_kv;
     hipStream_t st = (hipStream_t)stream;
     // 8 waves per block (2 per SIMD): dQ pass = 256 query rows per block, dK/dV pass = 128 keys per block (16 per wave)
-    dim3 grid_dq((S + 255) / 256, H, B), grid_dkv((S + 127) / 128, H, B);
+    // and one block per KEY/VALUE head (it walks the head's H / H_kv query heads)
+    dim3 grid_dq((S + 255) / 256, H, B), grid_dkv((S + 127) / 128, H_kv, B);
     const int smem_dq = 2 * (2 * 64 * HD * 2 + HD * 128);
     const int smem_dkv = 2 * (2 * 64 * HD * 2 + 2 * HD * 128 + 1024);
 #define LAUNCH_BWD(HD_, C_)                                                                                    \
@@ -513,4 +530,13 @@ extern "C" int rv_attn_bwd(const void* q, int64_t ld_q, const void* k, int64_t l
     else { if (causal) LAUNCH_BWD(64, true); else LAUNCH_BWD(64, false); }
 #undef LAUNCH_BWD
     return rv_check_launch();
+}
+
+extern "C" int rv_attn_bwd(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v,
+                           const void* o, int64_t ld_o, const void* dout, int64_t ld_do, const void* qT, const void* kT,
+                           const void* doT, const float* lse, float* delta, void* dq, int64_t ld_dq, void* dk,
+                           int64_t ld_dk, void* dv, int64_t ld_dv, const int32_t* lens, int B, int H, int S, int S_pad,
+                           int HD, int causal, float scale, const void* zeros16, void* stream) {
+    return rv_attn_bwd_gqa(q, ld_q, k, ld_k, v, ld_v, o, ld_o, dout, ld_do, qT, kT, doT, lse, delta, dq, ld_dq, dk, ld_dk, dv, ld_dv,
+                           lens, B, H, H, S, S_pad, HD, causal, scale, zeros16, stream);
 }

@@ -38,6 +38,7 @@ struct GemmParams {
 DEVINL float apply_act(float x, int act) {
     if (act == RV_ACT_QUICK_GELU) return x / (1.f + __expf(-1.702f * x));
     if (act == RV_ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+    if (act == RV_ACT_GELU_TANH) return 0.5f * x * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
     return x;
 }
 

@@ -377,6 +377,30 @@ __global__ void gelu_bwd_kernel(const bf16* dy, const bf16* x, bf16* dx, long n8
     st8(dx + i * 8, o);
 }
 
+__global__ void gelu_tanh_fwd_kernel(const bf16* x, bf16* y, long n8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    float v[8], o[8];
+    ld8(x + i * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = 0.5f * v[j] * (1.f + tanhf(0.7978845608028654f * (v[j] + 0.044715f * v[j] * v[j] * v[j])));
+    st8(y + i * 8, o);
+}
+__global__ void gelu_tanh_bwd_kernel(const bf16* dy, const bf16* x, bf16* dx, long n8) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    float v[8], g[8], o[8];
+    ld8(x + i * 8, v);
+    ld8(dy + i * 8, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x2 = v[j] * v[j];
+        const float t = tanhf(0.7978845608028654f * (v[j] + 0.044715f * v[j] * x2));
+        o[j] = g[j] * (0.5f * (1.f + t) + 0.5f * v[j] * (1.f - t * t) * 0.7978845608028654f * (1.f + 0.134145f * x2));
+    }
+    st8(dx + i * 8, o);
+}
+
 // ------------------------------------------------------------------------------------------------ cross entropy
 __global__ __launch_bounds__(TPB) void cross_entropy_kernel(const bf16* logits, long ld, const int64_t* labels, float* loss_rows,
                                                             bf16* dlogits, long ld_d, int V, float inv_count) {
@@ -473,6 +497,35 @@ __global__ void segment_sum_rows_kernel(const bf16* src, long ld_src, const int*
         }
         st8(o + e, acc);
     }
+}
+
+__global__ void weighted_segment_sum_rows_kernel(const bf16* src, long ld_src, const int* seg_off, const int* pos, const float* w,
+                                                 const int* out_row, bf16* out, long ld_out, int d) {
+    const int s = blockIdx.x;
+    const int j0 = seg_off[s], j1 = seg_off[s + 1];
+    bf16* o = out + (long)out_row[s] * ld_out;
+    for (int e = threadIdx.x * 8; e < d; e += blockDim.x * 8) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int j = j0; j < j1; ++j) {
+            float v[8];
+            ld8(src + (long)pos[j] * ld_src + e, v);
+            const float wj = w[j];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += wj * v[i];
+        }
+        st8(o + e, acc);
+    }
+}
+
+__global__ void add_pos_rows_kernel(bf16* x, const bf16* pos, long total, long per_image) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float a[8], b[8];
+    ld8(x + i * 8, a);
+    ld8(pos + (i % per_image) * 8, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += b[j];
+    st8(x + i * 8, a);
 }
 
 // ------------------------------------------------------------------------------------------------ CLIP embeddings
@@ -744,8 +797,32 @@ extern "C" int rv_segment_sum_rows(const void* src, int64_t ld_src, const int32_
     hipLaunchKernelGGL(segment_sum_rows_kernel, dim3(nseg), dim3(256), 0, ST, (const bf16*)src, (long)ld_src, seg_off, pos, out_row, (bf16*)out, (long)ld_out, d);
     return rv_check_launch();
 }
+extern "C" int rv_weighted_segment_sum_rows(const void* src, int64_t ld_src, const int32_t* seg_off, const int32_t* pos, const float* w,
+                                            const int32_t* out_row, int nseg, void* out, int64_t ld_out, int d, void* stream) {
+    if (!src || !seg_off || !pos || !w || !out_row || !out || nseg <= 0 || d <= 0 || (d & 7) || (ld_src & 7) || (ld_out & 7)) return RV_ERR_ARG;
+    if ((((uintptr_t)src) | ((uintptr_t)out)) & 15) return RV_ERR_ARG;
+    hipLaunchKernelGGL(weighted_segment_sum_rows_kernel, dim3(nseg), dim3(256), 0, ST, (const bf16*)src, (long)ld_src, seg_off, pos, w,
+                       out_row, (bf16*)out, (long)ld_out, d);
+    return rv_check_launch();
+}
+extern "C" int rv_add_pos_rows(void* x, const void* pos, int n, int P, int d, void* stream) {
+    if (!x || !pos || n <= 0 || P <= 0 || d <= 0 || (d & 7) || ((((uintptr_t)x) | ((uintptr_t)pos)) & 15)) return RV_ERR_ARG;
+    const long per = (long)P * d / 8, total = per * n;
+    hipLaunchKernelGGL(add_pos_rows_kernel, dim3(nblocks(total, 256)), dim3(256), 0, ST, (bf16*)x, (const bf16*)pos, total, per);
+    return rv_check_launch();
+}
+extern "C" int rv_gelu_tanh_fwd(const void* x, void* y, int64_t n, void* stream) {
+    if (!x || !y || n <= 0 || (n & 7)) return RV_ERR_ARG;
+    hipLaunchKernelGGL(gelu_tanh_fwd_kernel, dim3(nblocks(n / 8, 256)), dim3(256), 0, ST, (const bf16*)x, (bf16*)y, (long)(n / 8));
+    return rv_check_launch();
+}
+extern "C" int rv_gelu_tanh_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream) {
+    if (!dy || !x || !dx || n <= 0 || (n & 7)) return RV_ERR_ARG;
+    hipLaunchKernelGGL(gelu_tanh_bwd_kernel, dim3(nblocks(n / 8, 256)), dim3(256), 0, ST, (const bf16*)dy, (const bf16*)x, (bf16*)dx, (long)(n / 8));
+    return rv_check_launch();
+}
 extern "C" int rv_im2col_patches(const void* pix, void* out, int n, int H, int W, int p, int Kp, void* stream) {
-    if (!pix || !out || n <= 0 || p <= 0 || H % p || W % p || Kp < 3 * p * p) return RV_ERR_ARG;
+    if (!pix || !out || n <= 0 || p <= 0 || H < p || W < p || Kp < 3 * p * p) return RV_ERR_ARG;
     const long total = (long)n * (H / p) * (W / p) * Kp;
     hipLaunchKernelGGL(im2col_kernel, dim3(nblocks(total, 256)), dim3(256), 0, ST, (const bf16*)pix, (bf16*)out, n, H, W, p, Kp);
     return rv_check_launch();

@@ -41,11 +41,22 @@ class LlavaEngine:
         self.aspect = image_aspect_ratio
         self.pinpoints = image_grid_pinpoints
         self.max_len = max_len
-        self.eps = rms_eps
-        self.theta = rope_theta
+        self.eps = self.l.get("rms_eps", rms_eps)
+        self.theta = self.l.get("rope_theta", rope_theta)
+        self.hd = self.l["d"] // self.l["heads"]
+        self.Hkv = self.l.get("kv_heads", self.l["heads"])       # grouped-query attention (Qwen2)
+        self.kvd = self.Hkv * self.hd
+        self.siglip = self.v.get("kind") == "siglip"
+        self.has_cls = not self.siglip
+        self.ln_eps = 1e-6 if self.siglip else 1e-5               # siglip_encoder.py:83 / CLIP config default
+        vhd = self.v["d"] // self.v["heads"]
+        self.vhd_pad = vhd if vhd in (64, 128) else (64 if vhd < 64 else 128)
+        assert vhd <= 128
+        self._vis_pad = {}
         self.with_newline = "unpad" in merge_type
         self.side = self.v["image"] // self.v["patch"]
         self.P = self.side * self.side
+        self.N_vis = self.P + (1 if self.has_cls else 0)
         self.kp = _ru(3 * self.v["patch"] ** 2, 8)
         self.train_tower = train_vision_tower
         self.lora = dict(lora) if lora else None   # {"r": 64, "alpha": 16, "dropout": 0.05}
@@ -53,7 +64,7 @@ class LlavaEngine:
         if self.lora:
             # LoRA (BASELINE config 5): the language model is a frozen bf16 store; only adapters + projector are
             # trainable, so gradients / AdamW state / the DP all-reduce cover ~2 % of the parameters
-            assert not train_vision_tower
+            assert not train_vision_tower and self.Hkv == self.l["heads"] and not self.l.get("qkv_bias")
             r = self.lora["r"]
             self.lora_scale = self.lora.get("alpha", 16) / r
             self.lora_p = float(self.lora.get("dropout", 0.0))
@@ -117,25 +128,32 @@ class LlavaEngine:
             if flat is not None:
                 return {}          # the base weights of a LoRA run have no gradients
             f = self.base
+        out = {}
+        if self.l.get("qkv_bias"):
+            out["bqkv"] = f.fused(p + "self_attn.q_proj.bias", p + "self_attn.v_proj.bias", 1, d + 2 * self.kvd, flat).view(-1)
         return dict(
+            out,
             ln1=f.view(p + "input_layernorm.weight", flat),
-            qkv=f.fused(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", 3 * d, d, flat),
+            qkv=f.fused(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", d + 2 * self.kvd, d, flat),
             o=f.view(p + "self_attn.o_proj.weight", flat),
             ln2=f.view(p + "post_attention_layernorm.weight", flat),
             gu=f.fused(p + "mlp.gate_proj.weight", p + "mlp.up_proj.weight", 2 * F, d, flat),
             down=f.view(p + "mlp.down_proj.weight", flat),
         )
 
-    def weights_changed(self):
-        """Call after any in-place edit of the flat parameters (load_state_dict, optimizer step)."""
-        self._patch_w = None
+    def weights_changed(self, tower=True):
+        """Call after any in-place edit of the flat parameters (load_state_dict, optimizer step): drops the derived
+        copies of tower weights (padded patch / attention projections) when the tower may have changed."""
+        if tower:
+            self._patch_w = None
+            self._vis_pad = {}
 
     def rope_table(self, S):
         if S not in self._rope:
             self._rope[S] = ops.rope_table(S, self.l["d"] // self.l["heads"], self.theta, self.device)
         return self._rope[S]
 
-    # ------------------------------------------------------------------ vision tower (frozen, forward only)
+    # ------------------------------------------------------------------ vision tower
     def _vision_prepare(self):
         if self._patch_w is None:
             w = self.vis.view(VP + "embeddings.patch_embedding.weight").reshape(self.v["d"], -1)
@@ -143,43 +161,79 @@ class LlavaEngine:
             pw[:, :w.shape[1]] = w
             self._patch_w = pw
 
+    def _vis_attn_weights(self, i):
+        """(wqkv [3*H*hp, dv], bqkv [3*H*hp], wo [dv, H*hp]) of tower layer i.  The attention kernels take head_dim 64 or
+        128; for any other head_dim (SigLIP-so400m: 72, siglip_encoder.py:185) every head is zero-padded to hp in derived
+        copies of the projection weights, so q/k/v come out of the fused GEMM already padded: the padded lanes are exact
+        zeros in QK^T and PV and the softmax scale stays head_dim^-0.5."""
+        v, f = self.v, self.vis
+        dv, H = v["d"], v["heads"]
+        hd, hp = dv // H, self.vhd_pad
+        p = VP + f"encoder.layers.{i}."
+        wqkv = f.fused(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", 3 * dv, dv)
+        bqkv = f.fused(p + "self_attn.q_proj.bias", p + "self_attn.v_proj.bias", 1, 3 * dv).view(-1)
+        wo = f.view(p + "self_attn.out_proj.weight")
+        if hp == hd:
+            return wqkv, bqkv, wo
+        c = self._vis_pad.get(i)
+        if c is None:
+            wp = torch.zeros(3, H, hp, dv, dtype=BF16, device=self.device)
+            wp[:, :, :hd] = wqkv.view(3, H, hd, dv)
+            bp = torch.zeros(3, H, hp, dtype=BF16, device=self.device)
+            bp[:, :, :hd] = bqkv.view(3, H, hd)
+            op = torch.zeros(dv, H, hp, dtype=BF16, device=self.device)
+            op[:, :, :hd] = wo.view(dv, H, hd)
+            c = (wp.view(3 * H * hp, dv), bp.view(-1), op.view(dv, H * hp))
+            self._vis_pad[i] = c
+        return c
+
     def vision_forward(self, pixels, save=None):
-        """pixels bf16 [n,3,H,W] -> hidden_states[-2] as rows [n*(P+1), dv] (clip_encoder.py:68-79, select_layer -2).
-        With `save` (tower tunable) the per-layer activations needed by vision_backward are kept."""
+        """pixels bf16 [n,3,H,W] -> the tower's selected hidden state as rows [n*N, dv]:
+          CLIP   (clip_encoder.py:68-79): hidden_states[-2], N = P+1 (class token first);
+          SigLIP (siglip_encoder.py:568-590): hidden_states[-1] of the encoder WITHOUT its last layer, N = P = 729
+        -- both are 'run all layers but the last'.  With `save` (tower tunable) the activations vision_backward needs are kept."""
         v, f = self.v, self.vis
         self._vision_prepare()
         n = pixels.shape[0]
         dv, H = v["d"], v["heads"]
-        hd = dv // H
-        N = self.P + 1
+        hd, hp = dv // H, self.vhd_pad
+        dvp = H * hp
+        N = self.N_vis
         n_pad = _ru(N, 64)
         keep = save is not None
+        eps = self.ln_eps
         cols = ops.im2col_patches(pixels, v["patch"], self.kp)
-        po = ops.gemm_nt(cols, self._patch_w)
-        e = ops.clip_embed(po, f.view(VP + "embeddings.class_embedding"), f.view(VP + "embeddings.position_embedding.weight"),
-                           n, self.P, dv)
-        ln = lambda t, w, b: ops.layernorm_fwd(t, f.view(w), f.view(b), save_stats=keep)
-        r = ln(e, VP + "pre_layrnorm.weight", VP + "pre_layrnorm.bias")
-        x, st0 = r if keep else (r, None)
+        ln = lambda t, w, b: ops.layernorm_fwd(t, f.view(w), f.view(b), eps=eps, save_stats=keep)
+        if self.siglip:
+            e = ops.gemm_nt(cols, self._patch_w, bias=f.view(VP + "embeddings.patch_embedding.bias"))
+            x = ops.add_pos_rows(e, f.view(VP + "embeddings.position_embedding.weight"), n, self.P)
+            st0 = None
+        else:
+            po = ops.gemm_nt(cols, self._patch_w)
+            e = ops.clip_embed(po, f.view(VP + "embeddings.class_embedding"), f.view(VP + "embeddings.position_embedding.weight"),
+                               n, self.P, dv)
+            r = ln(e, VP + "pre_layrnorm.weight", VP + "pre_layrnorm.bias")
+            x, st0 = r if keep else (r, None)
+        act_code = ops.ACT_GELU_TANH if self.siglip else ops.ACT_QUICK_GELU
+        act_fwd = ops.gelu_tanh_fwd if self.siglip else ops.quick_gelu_fwd
         layers = []
-        for i in range(v["layers"] - 1):  # hidden_states[-2] = input of the last layer
+        for i in range(v["layers"] - 1):
             p = VP + f"encoder.layers.{i}."
             r = ln(x, p + "layer_norm1.weight", p + "layer_norm1.bias")
             h, st1 = r if keep else (r, None)
-            wqkv = f.fused(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", 3 * dv, dv)
-            bqkv = f.fused(p + "self_attn.q_proj.bias", p + "self_attn.v_proj.bias", 1, 3 * dv).view(-1)
+            wqkv, bqkv, wo = self._vis_attn_weights(i)
             qkv = ops.gemm_nt(h, wqkv, bias=bqkv)
-            vT = ops.transpose_heads(qkv[:, 2 * dv:], n, N, H, hd, n_pad)
-            a, lse = ops.attn_fwd(qkv[:, :dv], qkv[:, dv:2 * dv], vT, n, N, H, hd, n_pad, causal=False)
-            x1 = ops.gemm_nt(a, f.view(p + "self_attn.out_proj.weight"), bias=f.view(p + "self_attn.out_proj.bias"), residual=x)
+            vT = ops.transpose_heads(qkv[:, 2 * dvp:], n, N, H, hp, n_pad)
+            a, lse = ops.attn_fwd(qkv[:, :dvp], qkv[:, dvp:2 * dvp], vT, n, N, H, hp, n_pad, causal=False, scale=hd ** -0.5)
+            x1 = ops.gemm_nt(a, wo, bias=f.view(p + "self_attn.out_proj.bias"), residual=x)
             r = ln(x1, p + "layer_norm2.weight", p + "layer_norm2.bias")
             h2, st2 = r if keep else (r, None)
             if keep:
                 z = ops.gemm_nt(h2, f.view(p + "mlp.fc1.weight"), bias=f.view(p + "mlp.fc1.bias"))
-                g = ops.quick_gelu_fwd(z)
+                g = act_fwd(z)
             else:
                 z = None
-                g = ops.gemm_nt(h2, f.view(p + "mlp.fc1.weight"), bias=f.view(p + "mlp.fc1.bias"), act=ops.ACT_QUICK_GELU)
+                g = ops.gemm_nt(h2, f.view(p + "mlp.fc1.weight"), bias=f.view(p + "mlp.fc1.bias"), act=act_code)
             x2 = ops.gemm_nt(g, f.view(p + "mlp.fc2.weight"), bias=f.view(p + "mlp.fc2.bias"), residual=x1)
             if keep:
                 layers.append(dict(x=x, st1=st1, h=h, qkv=qkv, a=a, lse=lse, x1=x1, st2=st2, h2=h2, z=z, g=g))
@@ -188,80 +242,115 @@ class LlavaEngine:
             save.update(v_cols=cols, v_e=e, v_st0=st0, v_layers=layers, v_n=n)
         return x
 
+    @staticmethod
+    def _put(dst, src, acc):
+        dst.add_(src) if acc else dst.copy_(src)
+
     def vision_backward(self, dx, c):
-        """Backward of vision_forward: dx = d hidden_states[-2] [n*(P+1), dv]; parameter grads -> flat grad views."""
+        """Backward of vision_forward: dx = d(selected hidden state) [n*N, dv]; parameter grads -> flat grad views."""
         v, f, G = self.v, self.vis, self.G
         n = c["v_n"]
         dv, H = v["d"], v["heads"]
-        hd = dv // H
-        N = self.P + 1
+        hd, hp = dv // H, self.vhd_pad
+        dvp = H * hp
+        padded = hp != hd
+        N = self.N_vis
         n_pad = _ru(N, 64)
         acc = self.grad_accum_started
         W = lambda name: f.view(name)
+        act_bwd = ops.gelu_tanh_bwd if self.siglip else ops.quick_gelu_bwd
         for i in reversed(range(v["layers"] - 1)):
             a = c["v_layers"][i]
             p = VP + f"encoder.layers.{i}."
             ops.bias_grad(dx, out=G(p + "mlp.fc2.bias"), accumulate=acc)
             dg = self._linear_bwd(dx, a["g"], W(p + "mlp.fc2.weight"), G(p + "mlp.fc2.weight"))
-            dz = ops.quick_gelu_bwd(dg, a["z"])
+            dz = act_bwd(dg, a["z"])
             ops.bias_grad(dz, out=G(p + "mlp.fc1.bias"), accumulate=acc)
             dh2 = self._linear_bwd(dz, a["h2"], W(p + "mlp.fc1.weight"), G(p + "mlp.fc1.weight"))
             ops.layernorm_bwd(dh2, a["x1"], W(p + "layer_norm2.weight"), a["st2"], G(p + "layer_norm2.weight"),
                               G(p + "layer_norm2.bias"), dx=dx, dx_add=True, accumulate=acc)
             ops.bias_grad(dx, out=G(p + "self_attn.out_proj.bias"), accumulate=acc)
-            da = self._linear_bwd(dx, a["a"], W(p + "self_attn.out_proj.weight"), G(p + "self_attn.out_proj.weight"))
+            wqkv, bqkv, wo = self._vis_attn_weights(i)
+            gqkv = f.fused(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", 3 * dv, dv, self.grads)
+            gb = f.fused(p + "self_attn.q_proj.bias", p + "self_attn.v_proj.bias", 1, 3 * dv, self.grads).view(-1)
+            if padded:   # gradients of the padded copies, valid lanes folded back into the flat views
+                gwo = ops.gemm(dx, a["a"], ta=True, tb=True)
+                self._put(G(p + "self_attn.out_proj.weight").view(dv, H, hd), gwo.view(dv, H, hp)[:, :, :hd], acc)
+                da = ops.gemm(dx, wo, tb=True)
+            else:
+                da = self._linear_bwd(dx, a["a"], wo, G(p + "self_attn.out_proj.weight"))
             qkv = a["qkv"]
             dqkv = torch.empty_like(qkv)
-            ops.attn_bwd(qkv[:, :dv], qkv[:, dv:2 * dv], qkv[:, 2 * dv:], a["a"], da, a["lse"], n, N, H, hd, n_pad, False,
-                         dq=dqkv[:, :dv], dk=dqkv[:, dv:2 * dv], dv=dqkv[:, 2 * dv:])
-            gb = f.fused(p + "self_attn.q_proj.bias", p + "self_attn.v_proj.bias", 1, 3 * dv, self.grads).view(-1)
-            ops.bias_grad(dqkv, out=gb, accumulate=acc)
-            wqkv = f.fused(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", 3 * dv, dv)
-            gqkv = f.fused(p + "self_attn.q_proj.weight", p + "self_attn.v_proj.weight", 3 * dv, dv, self.grads)
-            dh = self._linear_bwd(dqkv, a["h"], wqkv, gqkv)
+            ops.attn_bwd(qkv[:, :dvp], qkv[:, dvp:2 * dvp], qkv[:, 2 * dvp:], a["a"], da, a["lse"], n, N, H, hp, n_pad, False,
+                         scale=hd ** -0.5, dq=dqkv[:, :dvp], dk=dqkv[:, dvp:2 * dvp], dv=dqkv[:, 2 * dvp:])
+            if padded:
+                gbp = ops.bias_grad(dqkv)
+                self._put(gb.view(3, H, hd), gbp.view(3, H, hp)[:, :, :hd], acc)
+                gwp = ops.gemm(dqkv, a["h"], ta=True, tb=True)
+                self._put(gqkv.view(3, H, hd, dv), gwp.view(3, H, hp, dv)[:, :, :hd], acc)
+                dh = ops.gemm(dqkv, wqkv, tb=True)
+            else:
+                ops.bias_grad(dqkv, out=gb, accumulate=acc)
+                dh = self._linear_bwd(dqkv, a["h"], wqkv, gqkv)
             ops.layernorm_bwd(dh, a["x"], W(p + "layer_norm1.weight"), a["st1"], G(p + "layer_norm1.weight"),
                               G(p + "layer_norm1.bias"), dx=dx, dx_add=True, accumulate=acc)
             c["v_layers"][i] = None
             self._bucket_done(p + "layer_norm1.weight", p + "mlp.fc2.bias")
-        de = ops.layernorm_bwd(dx, c["v_e"], W(VP + "pre_layrnorm.weight"), c["v_st0"], G(VP + "pre_layrnorm.weight"),
-                               G(VP + "pre_layrnorm.bias"), accumulate=acc)
+        if self.siglip:
+            de = dx
+        else:
+            de = ops.layernorm_bwd(dx, c["v_e"], W(VP + "pre_layrnorm.weight"), c["v_st0"], G(VP + "pre_layrnorm.weight"),
+                                   G(VP + "pre_layrnorm.bias"), accumulate=acc)
         # embeddings: position table = sum over images, class token = rows t = 0, patch conv = wgrad over im2col rows
         de2 = de.view(n, N * dv)
         ops.bias_grad(de2, out=G(VP + "embeddings.position_embedding.weight").view(-1), accumulate=acc)
-        ops.bias_grad(de2[:, :dv], out=G(VP + "embeddings.class_embedding"), accumulate=acc)
-        drop_cls = (torch.arange(n * self.P, device=self.device, dtype=torch.int32)
-                    + torch.arange(n, device=self.device, dtype=torch.int32).repeat_interleave(self.P) + 1)
-        dpo = ops.gather_rows(drop_cls, dv, de)
+        if self.siglip:
+            ops.bias_grad(de, out=G(VP + "embeddings.patch_embedding.bias"), accumulate=acc)
+            dpo = de
+        else:
+            ops.bias_grad(de2[:, :dv], out=G(VP + "embeddings.class_embedding"), accumulate=acc)
+            drop_cls = (torch.arange(n * self.P, device=self.device, dtype=torch.int32)
+                        + torch.arange(n, device=self.device, dtype=torch.int32).repeat_interleave(self.P) + 1)
+            dpo = ops.gather_rows(drop_cls, dv, de)
         dwp = ops.gemm(dpo, c["v_cols"], ta=True, tb=True)
         gp = G(VP + "embeddings.patch_embedding.weight").view(dv, -1)
-        k = gp.shape[1]
-        gp.add_(dwp[:, :k]) if acc else gp.copy_(dwp[:, :k])
-        # the last encoder layer and post_layernorm do not feed hidden_states[-2]: their gradients are zero
+        self._put(gp, dwp[:, :gp.shape[1]], acc)
+        # the last encoder layer and post_layernorm do not feed the selected hidden state: their gradients are zero
         last = VP + f"encoder.layers.{v['layers'] - 1}."
         s0, _ = self.lm.span(last + "layer_norm1.weight", last + "layer_norm1.weight")
         _, e1 = self.lm.span(VP + "post_layernorm.bias", VP + "post_layernorm.bias")
         if not acc:
             self.grads[s0:e1].zero_()
-        self._bucket_done(VP + "embeddings.class_embedding", VP + "pre_layrnorm.bias")
+        first = VP + ("embeddings.patch_embedding.weight" if self.siglip else "embeddings.class_embedding")
+        self._bucket_done(first, VP + ("embeddings.position_embedding.weight" if self.siglip else "pre_layrnorm.bias"))
         self._bucket_done(last + "layer_norm1.weight", VP + "post_layernorm.bias")
 
-    def encode_images(self, pixels, save=None):
+    def encode_images(self, pixels, save=None, plan=None):
         """encode_images (llava_arch.py:192-196): tower (patch features, CLS dropped) then mlp2x_gelu projector.
-        Returns the feature table [n*P + 1, d]; its last row is reserved for image_newline."""
+        Returns the feature table [n*P + n_extra + 1, d]: projector rows, then the rows anyres_max creates by bilinear
+        down-sampling (llava_arch.py:381-392; a 4-tap weighted gather of projector rows), then image_newline."""
         n = pixels.shape[0]
+        rs = (plan or {}).get("resample")
+        n_extra = plan["n_extra_rows"] if rs else 0
         d = self.l["d"]
         hid = self.vision_forward(pixels, save=save if (self.train_tower and save is not None) else None)
-        drop_cls = (torch.arange(n * self.P, device=self.device, dtype=torch.int32)
-                    + torch.arange(n, device=self.device, dtype=torch.int32).repeat_interleave(self.P) + 1)
-        f0 = ops.gather_rows(drop_cls, self.v["d"], hid)
+        if self.has_cls:
+            drop_cls = (torch.arange(n * self.P, device=self.device, dtype=torch.int32)
+                        + torch.arange(n, device=self.device, dtype=torch.int32).repeat_interleave(self.P) + 1)
+            f0 = ops.gather_rows(drop_cls, self.v["d"], hid)
+        else:
+            f0 = hid
         z1 = ops.gemm_nt(f0, self.W("model.mm_projector.0.weight"), bias=self.W("model.mm_projector.0.bias"))
         a1 = ops.gelu_fwd(z1)
-        table = torch.empty(n * self.P + 1, d, dtype=BF16, device=self.device)
+        table = torch.empty(n * self.P + n_extra + 1, d, dtype=BF16, device=self.device)
         ops.gemm_nt(a1, self.W("model.mm_projector.2.weight"), bias=self.W("model.mm_projector.2.bias"), out=table[:n * self.P])
+        if rs:
+            t = lambda k: torch.from_numpy(rs[k]).to(self.device)
+            ops.weighted_segment_sum_rows(table, t("fwd_off"), t("fwd_pos"), t("fwd_w"), t("fwd_out"), table)
         if self.with_newline:
-            table[n * self.P].copy_(self.W("model.image_newline"))
+            table[n * self.P + n_extra].copy_(self.W("model.image_newline"))
         else:
-            table[n * self.P].zero_()
+            table[n * self.P + n_extra].zero_()
         if save is not None:
             save.update(f0=f0, z1=z1, a1=a1)
         return table
@@ -270,17 +359,34 @@ class LlavaEngine:
     def plan(self, input_ids, attention_mask, labels, images, image_sizes=None):
         """Host-side index planning (numpy); images: list of [3,H,W] or [T,3,H,W] tensors."""
         tiles = [1 if im.ndim == 3 else im.shape[0] for im in images]
+        n_proj = sum(tiles) * self.P
+        extra = dict(next=n_proj, src=[], w=[])     # rows created by anyres_max down-sampling follow the projector rows
         rows, r0 = [], 0
         for i, t in enumerate(tiles):
             rows.append(merged_feature_rows(r0, t, self.side, self.merge_type, self.aspect,
                                             tuple(image_sizes[i]) if image_sizes is not None else None, self.pinpoints,
-                                            self.v["image"]))
+                                            self.v["image"], extra=extra))
             r0 += t * self.P
+        n_extra = extra["next"] - n_proj
         ids = np.asarray(input_ids)
         am = np.asarray(attention_mask).astype(bool) if attention_mask is not None else np.ones_like(ids, dtype=bool)
         lab = np.asarray(labels) if labels is not None else np.full_like(ids, -100)
-        plan = build_splice_plan(ids, am, lab, rows, r0, self.max_len)
-        plan["n_feat_rows"] = r0
+        plan = build_splice_plan(ids, am, lab, rows, n_proj + n_extra, self.max_len)
+        plan["n_feat_rows"] = n_proj + n_extra
+        plan["n_proj_rows"] = n_proj
+        plan["n_extra_rows"] = n_extra
+        if n_extra:
+            src = np.concatenate(extra["src"]).reshape(-1)            # [4 * n_extra] projector rows
+            w = np.concatenate(extra["w"]).reshape(-1).astype(np.float32)
+            assert (plan["feat_pos"][np.unique(src)] < 0).all()       # a down-sampled grid's sources are never spliced directly
+            order = np.argsort(src, kind="stable")
+            usrc, starts = np.unique(src[order], return_index=True)
+            plan["resample"] = dict(
+                fwd_off=np.arange(0, 4 * n_extra + 1, 4, dtype=np.int32), fwd_pos=src.astype(np.int32), fwd_w=w,
+                fwd_out=(n_proj + np.arange(n_extra)).astype(np.int32),
+                # adjoint: for every source row, the (created row, weight) pairs it feeds
+                adj_off=np.concatenate([starts, [src.shape[0]]]).astype(np.int32),
+                adj_pos=(n_proj + order // 4).astype(np.int32), adj_w=w[order], adj_out=usrc.astype(np.int32))
         return plan
 
     def forward(self, input_ids, attention_mask, labels, images, image_sizes=None, want_logits=False, loss_scale=1.0):
@@ -288,14 +394,14 @@ class LlavaEngine:
         dev = self.device
         l = self.l
         d, F, H, V, L = l["d"], l["ffn"], l["heads"], l["vocab"], l["layers"]
-        hd = d // H
+        hd, Hkv, kvd = self.hd, self.Hkv, self.kvd
         plan = self.plan(input_ids, attention_mask, labels, images, image_sizes)
         self.lora_step += 1
         pix = torch.cat([(im if im.ndim == 4 else im[None]) for im in images], 0)
         pix = pix.to(dev, non_blocking=True)
         pix = pix if pix.dtype == BF16 else ops.to_bf16(pix.float())
         ctx = dict(plan=plan)
-        table = self.encode_images(pix.contiguous(), save=ctx)
+        table = self.encode_images(pix.contiguous(), save=ctx, plan=plan)
         B = len(images)
         S = plan["S"]
         M = B * S
@@ -312,10 +418,10 @@ class LlavaEngine:
             if self.lora:
                 qkv = self._lora_linear(h1, lv["qkv"], i, self._MODS_QKV(d), sv)
             else:
-                qkv = ops.gemm_nt(h1, lv["qkv"])
-            ops.rope_inplace(qkv, cs, S, H, hd, 2, 1)
-            vT = ops.transpose_heads(qkv[:, 2 * d:], B, S, H, hd, s_pad)
-            attn, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d:2 * d], vT, B, S, H, hd, s_pad, causal=True, lens=lens)
+                qkv = ops.gemm_nt(h1, lv["qkv"], bias=lv.get("bqkv"))
+            ops.rope_inplace(qkv, cs, S, H + Hkv, hd, 1, 1)          # q heads then k heads: one run of H + Hkv heads
+            vT = ops.transpose_heads(qkv[:, d + kvd:], B, S, Hkv, hd, s_pad)
+            attn, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d:d + kvd], vT, B, S, H, hd, s_pad, causal=True, lens=lens, kv_heads=Hkv)
             if self.lora:
                 x_mid = self._lora_linear(attn, lv["o"], i, (("self_attn.o_proj", 0, d),), sv, residual=x)
             else:
@@ -436,7 +542,7 @@ class LlavaEngine:
         assert c is not None, "forward() first"
         l = self.l
         d, F, H, V, L = l["d"], l["ffn"], l["heads"], l["vocab"], l["layers"]
-        hd = d // H
+        hd, Hkv, kvd = self.hd, self.Hkv, self.kvd
         B, S, M, s_pad, lens = c["B"], c["S"], c["M"], c["s_pad"], c["lens"]
         acc = self.grad_accum_started
         cs = self.rope_table(S)
@@ -459,9 +565,11 @@ class LlavaEngine:
             dattn = self._lm_linear_bwd(dx, a["attn"], lv["o"], gv.get("o"), i, (("self_attn.o_proj", 0, d),), sv)
             qkv = a["qkv"]
             dqkv = torch.empty_like(qkv)
-            ops.attn_bwd(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], a["attn"], dattn, a["lse"], B, S, H, hd, s_pad, True,
-                         lens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:2 * d], dv=dqkv[:, 2 * d:])
-            ops.rope_inplace(dqkv, cs, S, H, hd, 2, -1)
+            ops.attn_bwd(qkv[:, :d], qkv[:, d:d + kvd], qkv[:, d + kvd:], a["attn"], dattn, a["lse"], B, S, H, hd, s_pad, True,
+                         lens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:d + kvd], dv=dqkv[:, d + kvd:], kv_heads=Hkv)
+            ops.rope_inplace(dqkv, cs, S, H + Hkv, hd, 1, -1)
+            if "bqkv" in gv:
+                ops.bias_grad(dqkv, out=gv["bqkv"], accumulate=acc)
             dh1 = self._lm_linear_bwd(dqkv, a["h1"], lv["qkv"], gv.get("qkv"), i, self._MODS_QKV(d), sv)
             ops.rmsnorm_bwd(dh1, a["x"], lv["ln1"], a["rstd1"], dx=dx, dx_add=True, dw=gv.get("ln1"), dw_accumulate=acc)
             c["layers"][i] = None  # free this layer's activations
@@ -477,6 +585,11 @@ class LlavaEngine:
         n_rows = plan["n_feat_rows"]
         fpos = torch.from_numpy(plan["feat_pos"]).to(dev)
         dfeat = ops.gather_rows(fpos, d, dx)
+        rs = plan.get("resample")
+        if rs:   # adjoint of the bilinear down-sampling: gradients of the created rows flow to their 4 source rows
+            t = lambda k: torch.from_numpy(rs[k]).to(dev)
+            ops.weighted_segment_sum_rows(dfeat, t("adj_off"), t("adj_pos"), t("adj_w"), t("adj_out"), dfeat)
+            dfeat = dfeat[:plan["n_proj_rows"]]
         g = self.G
         ops.bias_grad(dfeat, out=g("model.mm_projector.2.bias"), accumulate=acc)
         da1 = self._linear_bwd(dfeat, c["a1"], self.W("model.mm_projector.2.weight"), g("model.mm_projector.2.weight"))
@@ -510,11 +623,13 @@ class LlavaEngine:
         last = "model.image_newline" if self.with_newline else "model.mm_projector.2.bias"
         self._bucket_done("model.mm_projector.0.weight" if frozen_lm else "model.embed_tokens.weight", last)
         if self.train_tower:
-            n_img = c["v_n"]
-            N = self.P + 1
-            put = torch.full((n_img, N), -1, dtype=torch.int32, device=dev)
-            put[:, 1:] = torch.arange(n_img * self.P, device=dev, dtype=torch.int32).view(n_img, self.P)
-            dhid = ops.gather_rows(put.view(-1), self.v["d"], df0)   # CLS rows receive zero
+            if self.has_cls:
+                n_img = c["v_n"]
+                put = torch.full((n_img, self.N_vis), -1, dtype=torch.int32, device=dev)
+                put[:, 1:] = torch.arange(n_img * self.P, device=dev, dtype=torch.int32).view(n_img, self.P)
+                dhid = ops.gather_rows(put.view(-1), self.v["d"], df0)   # CLS rows receive zero
+            else:
+                dhid = df0
             self.vision_backward(dhid, c)
         self.ctx = None
         self.grad_accum_started = True
@@ -576,7 +691,7 @@ class LlavaEngine:
         for s, e, glr, gwd in self.param_groups(lr, weight_decay, mm_projector_lr, mm_vision_tower_lr=mm_vision_tower_lr):
             ops.adamw(self.lm.flat[s:e], self.master[s:e], self.grads[s:e], self.m[s:e], self.vv[s:e], glr, betas[0], betas[1],
                       eps, gwd, self.opt_step, gscale=coef)
-        self.weights_changed()
+        self.weights_changed(tower=self.train_tower)
         self.zero_grad()
 
     # ------------------------------------------------------------------ state dict (reference names)

@@ -17,7 +17,7 @@ _i64 = ctypes.c_int64
 _i32 = ctypes.c_int
 _f32 = ctypes.c_float
 
-ACT_NONE, ACT_QUICK_GELU, ACT_GELU = 0, 1, 2
+ACT_NONE, ACT_QUICK_GELU, ACT_GELU, ACT_GELU_TANH = 0, 1, 2, 3
 
 _SIGS = {
     "rv_gemm_nt_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i32, _i32, _i32,
@@ -42,6 +42,16 @@ _SIGS = {
     "rv_attn_bwd": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p,
                     _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i32, _i32,
                     _i32, _i32, _i32, _i32, _f32, _c_void_p, _c_void_p],
+    "rv_attn_fwd_gqa": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32,
+                        _i32, _i32, _i32, _f32, _c_void_p, _c_void_p],
+    "rv_attn_bwd_gqa": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p,
+                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i32, _i32,
+                        _i32, _i32, _i32, _i32, _i32, _f32, _c_void_p, _c_void_p],
+    "rv_gelu_tanh_fwd": [_c_void_p, _c_void_p, _i64, _c_void_p],
+    "rv_gelu_tanh_bwd": [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p],
+    "rv_weighted_segment_sum_rows": [_c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i32, _c_void_p, _i64, _i32,
+                                     _c_void_p],
+    "rv_add_pos_rows": [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p],
     "rv_swiglu_fwd": [_c_void_p, _i64, _c_void_p, _i64, _i32, _i32, _c_void_p],
     "rv_swiglu_bwd": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _i32, _c_void_p],
     "rv_gelu_fwd": [_c_void_p, _c_void_p, _i64, _c_void_p],

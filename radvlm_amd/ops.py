@@ -7,7 +7,7 @@ import math
 import torch
 
 from . import lib
-from .lib import ACT_GELU, ACT_NONE, ACT_QUICK_GELU  # noqa: F401
+from .lib import ACT_GELU, ACT_GELU_TANH, ACT_NONE, ACT_QUICK_GELU  # noqa: F401
 
 BF16 = torch.bfloat16
 
@@ -188,6 +188,20 @@ def quick_gelu_bwd(dy, x, dx=None):
     return dx
 
 
+def gelu_tanh_fwd(x, y=None):
+    assert x.is_contiguous()
+    y = torch.empty_like(x) if y is None else y
+    lib.call("rv_gelu_tanh_fwd", x, y, x.numel())
+    return y
+
+
+def gelu_tanh_bwd(dy, x, dx=None):
+    assert x.is_contiguous() and dy.is_contiguous()
+    dx = torch.empty_like(x) if dx is None else dx
+    lib.call("rv_gelu_tanh_bwd", dy, x, dx, x.numel())
+    return dx
+
+
 def bias_grad(dy, out=None, accumulate=False):
     """db[c] = sum_r dy[r, c]."""
     rows, cols = dy.shape
@@ -218,30 +232,34 @@ def rope_inplace(x, cos_sin, S, heads, hd, nsec, direction=1):
     return x
 
 
-def attn_fwd(q, k, vT, B, S, H, hd, s_pad, causal, lens=None, scale=None, out=None, lse=None):
-    """q, k: token-major [(B*S), H*hd] views; vT [B,H,hd,s_pad]. Returns (out [(B*S), H*hd], lse fp32 [B,H,s_pad])."""
+def attn_fwd(q, k, vT, B, S, H, hd, s_pad, causal, lens=None, scale=None, out=None, lse=None, kv_heads=None):
+    """q, k: token-major [(B*S), H*hd] / [(B*S), kv_heads*hd] views; vT [B,kv_heads,hd,s_pad].
+    Returns (out [(B*S), H*hd], lse fp32 [B,H,s_pad])."""
     scale = scale if scale is not None else 1.0 / math.sqrt(hd)
+    Hkv = kv_heads or H
     if out is None:
         out = torch.empty(B * S, H * hd, dtype=BF16, device=q.device)
     if lse is None:
         lse = torch.zeros(B, H, s_pad, dtype=torch.float32, device=q.device)
-    lib.call("rv_attn_fwd", q, q.stride(0), k, k.stride(0), vT, out, out.stride(0), lse, lens, B, H, S, s_pad, hd,
+    lib.call("rv_attn_fwd_gqa", q, q.stride(0), k, k.stride(0), vT, out, out.stride(0), lse, lens, B, H, Hkv, S, s_pad, hd,
              int(causal), scale, lib.zeros16(q.device))
     return out, lse
 
 
-def attn_bwd(q, k, v, o, dout, lse, B, S, H, hd, s_pad, causal, lens=None, scale=None, dq=None, dk=None, dv=None):
+def attn_bwd(q, k, v, o, dout, lse, B, S, H, hd, s_pad, causal, lens=None, scale=None, dq=None, dk=None, dv=None,
+             kv_heads=None):
     scale = scale if scale is not None else 1.0 / math.sqrt(hd)
     dev = q.device
+    Hkv = kv_heads or H
     qT = transpose_heads(q, B, S, H, hd, s_pad)
-    kT = transpose_heads(k, B, S, H, hd, s_pad)
+    kT = transpose_heads(k, B, S, Hkv, hd, s_pad)
     doT = transpose_heads(dout, B, S, H, hd, s_pad)
     delta = torch.zeros(B, H, s_pad, dtype=torch.float32, device=dev)
     dq = torch.empty(B * S, H * hd, dtype=BF16, device=dev) if dq is None else dq
-    dk = torch.empty(B * S, H * hd, dtype=BF16, device=dev) if dk is None else dk
-    dv = torch.empty(B * S, H * hd, dtype=BF16, device=dev) if dv is None else dv
-    lib.call("rv_attn_bwd", q, q.stride(0), k, k.stride(0), v, v.stride(0), o, o.stride(0), dout, dout.stride(0), qT, kT, doT,
-             lse, delta, dq, dq.stride(0), dk, dk.stride(0), dv, dv.stride(0), lens, B, H, S, s_pad, hd, int(causal), scale,
+    dk = torch.empty(B * S, Hkv * hd, dtype=BF16, device=dev) if dk is None else dk
+    dv = torch.empty(B * S, Hkv * hd, dtype=BF16, device=dev) if dv is None else dv
+    lib.call("rv_attn_bwd_gqa", q, q.stride(0), k, k.stride(0), v, v.stride(0), o, o.stride(0), dout, dout.stride(0), qT, kT, doT,
+             lse, delta, dq, dq.stride(0), dk, dk.stride(0), dv, dv.stride(0), lens, B, H, Hkv, S, s_pad, hd, int(causal), scale,
              lib.zeros16(dev))
     return dq, dk, dv
 
@@ -311,6 +329,22 @@ def segment_sum_rows(src, seg_off, pos, out_row, out):
         return out
     lib.call("rv_segment_sum_rows", src, src.stride(0), seg_off, pos, out_row, nseg, out, out.stride(0), src.shape[1])
     return out
+
+
+def weighted_segment_sum_rows(src, seg_off, pos, w, out_row, out):
+    """out[out_row[s]] = sum_{j in segment s} w[j] * src[pos[j]]  (bilinear taps / their adjoint)."""
+    nseg = out_row.numel()
+    if nseg == 0:
+        return out
+    lib.call("rv_weighted_segment_sum_rows", src, src.stride(0), seg_off, pos, w, out_row, nseg, out, out.stride(0), src.shape[1])
+    return out
+
+
+def add_pos_rows(x, pos, n, P):
+    """x [n*P, d] += pos [P, d] broadcast over images, in place."""
+    assert x.is_contiguous() and pos.is_contiguous() and x.shape[0] == n * P and pos.shape[0] == P
+    lib.call("rv_add_pos_rows", x, pos, n, P, x.shape[1])
+    return x
 
 
 def im2col_patches(pix, p, kp):

@@ -37,11 +37,15 @@ def lm_param_shapes(geo, with_newline=False):
     s["model.mm_projector.2.bias"] = (l["d"],)
     if with_newline:
         s["model.image_newline"] = (l["d"],)
+    kvd = l["d"] // l["heads"] * l.get("kv_heads", l["heads"])   # grouped-query k/v width (Qwen2)
     for i in range(l["layers"]):
         p = f"model.layers.{i}."
         s[p + "input_layernorm.weight"] = (l["d"],)
-        for n in ("q_proj", "k_proj", "v_proj"):
-            s[p + f"self_attn.{n}.weight"] = (l["d"], l["d"])
+        for n, rows in (("q_proj", l["d"]), ("k_proj", kvd), ("v_proj", kvd)):
+            s[p + f"self_attn.{n}.weight"] = (rows, l["d"])
+        if l.get("qkv_bias"):
+            for n, rows in (("q_proj", l["d"]), ("k_proj", kvd), ("v_proj", kvd)):
+                s[p + f"self_attn.{n}.bias"] = (rows,)
         s[p + "self_attn.o_proj.weight"] = (l["d"], l["d"])
         s[p + "post_attention_layernorm.weight"] = (l["d"],)
         s[p + "mlp.gate_proj.weight"] = (l["ffn"], l["d"])
@@ -77,13 +81,18 @@ def lora_trainable_shapes(geo, r, with_newline=False):
 
 def vision_param_shapes(geo):
     v = geo["vision"]
-    npos = (v["image"] // v["patch"]) ** 2 + 1
+    siglip = v.get("kind") == "siglip"   # siglip_encoder.py:148-174: conv bias, no class token, no pre-LN
+    npos = (v["image"] // v["patch"]) ** 2 + (0 if siglip else 1)
     s = OrderedDict()
-    s[VP + "embeddings.class_embedding"] = (v["d"],)
+    if not siglip:
+        s[VP + "embeddings.class_embedding"] = (v["d"],)
     s[VP + "embeddings.patch_embedding.weight"] = (v["d"], 3, v["patch"], v["patch"])
+    if siglip:
+        s[VP + "embeddings.patch_embedding.bias"] = (v["d"],)
     s[VP + "embeddings.position_embedding.weight"] = (npos, v["d"])
-    s[VP + "pre_layrnorm.weight"] = (v["d"],)
-    s[VP + "pre_layrnorm.bias"] = (v["d"],)
+    if not siglip:
+        s[VP + "pre_layrnorm.weight"] = (v["d"],)
+        s[VP + "pre_layrnorm.bias"] = (v["d"],)
     for i in range(v["layers"]):
         p = VP + f"encoder.layers.{i}."
         s[p + "layer_norm1.weight"] = (v["d"],)

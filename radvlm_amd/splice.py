@@ -57,9 +57,33 @@ def unpad_index(t, original_size):
     return t[:, pad:cw - pad]
 
 
+def bilinear_taps(h, w, oh, ow):
+    """The 4 taps of every output pixel of nn.functional.interpolate(x[None], [oh, ow], mode="bilinear") (align_corners
+    False, no antialias; llava_arch.py:389-391) as (idx int64 [oh*ow, 4] into the h*w source grid, weight fp32 [oh*ow, 4]).
+    Source coordinate = (in/out) * (dst + 0.5) - 0.5 clamped at 0, in fp32 like ATen's area_pixel_compute_source_index."""
+    def axis(n_in, n_out):
+        scale = np.float32(n_in) / np.float32(n_out)
+        src = np.maximum(scale * (np.arange(n_out, dtype=np.float32) + np.float32(0.5)) - np.float32(0.5), np.float32(0))
+        i0 = np.minimum(np.floor(src).astype(np.int64), n_in - 1)
+        i1 = np.minimum(i0 + 1, n_in - 1)
+        l1 = (src - i0.astype(np.float32)).astype(np.float32)
+        return i0, i1, (np.float32(1) - l1).astype(np.float32), l1
+    y0, y1, wy0, wy1 = axis(h, oh)
+    x0, x1, wx0, wx1 = axis(w, ow)
+    idx = np.stack([y0[:, None] * w + x0[None, :], y0[:, None] * w + x1[None, :],
+                    y1[:, None] * w + x0[None, :], y1[:, None] * w + x1[None, :]], axis=-1).reshape(-1, 4)
+    wt = np.stack([wy0[:, None] * wx0[None, :], wy0[:, None] * wx1[None, :],
+                   wy1[:, None] * wx0[None, :], wy1[:, None] * wx1[None, :]], axis=-1).reshape(-1, 4).astype(np.float32)
+    return idx, wt
+
+
 def merged_feature_rows(row0, n_tiles, side, merge_type="flat", aspect="square", image_size=None, pinpoints=None,
-                        tower_image_size=None):
-    """Index (into the projector-output row table) of every merged image token of ONE sample; NEWLINE = -1."""
+                        tower_image_size=None, extra=None):
+    """Index (into the feature row table) of every merged image token of ONE sample; NEWLINE = -1.
+
+    ``extra`` (dict with ``next``, ``src``, ``w``) collects the rows that anyres_max creates by bilinear down-sampling
+    (llava_arch.py:381-392): they get fresh table row ids starting at extra["next"], and their 4 (source row, weight)
+    taps are appended to extra["src"] / extra["w"] for the device-side weighted gather."""
     P = side * side
     rows = np.arange(row0, row0 + n_tiles * P, dtype=np.int64).reshape(n_tiles, P)
     if merge_type == "flat":
@@ -73,11 +97,24 @@ def merged_feature_rows(row0, n_tiles, side, merge_type="flat", aspect="square",
         else:
             gw, gh = 2, 2
         rest = rest.reshape(gh, gw, side, side)
-        if "maxpool2x2" in merge_type or ("anyres_max" in aspect and "unpad" in merge_type):
-            raise NotImplementedError("pooled / anyres_max merges change feature values, not only their order")
+        if "maxpool2x2" in merge_type:
+            raise NotImplementedError("maxpool2x2 merge (not used by any shipped recipe)")
         if "unpad" in merge_type:
             grid = rest.transpose(0, 2, 1, 3).reshape(gh * side, gw * side)
             grid = unpad_index(grid, image_size)
+            mx = re.match(r"anyres_max_(\d+)", aspect)
+            if mx:
+                hh, ww = grid.shape
+                times = math.sqrt(hh * ww / (int(mx.group(1)) * side ** 2))
+                if times > 1.1:
+                    if extra is None:
+                        raise ValueError("anyres_max down-sampling needs the `extra` collector")
+                    oh, ow = int(hh // times), int(ww // times)
+                    idx, wt = bilinear_taps(hh, ww, oh, ow)
+                    extra["src"].append(grid.reshape(-1)[idx])
+                    extra["w"].append(wt)
+                    grid = (extra["next"] + np.arange(oh * ow, dtype=np.int64)).reshape(oh, ow)
+                    extra["next"] += oh * ow
             nl = np.full((grid.shape[0], 1), NEWLINE, dtype=np.int64)
             rest = np.concatenate([grid, nl], axis=1).reshape(-1)
         else:

@@ -101,6 +101,41 @@ def test_toy_vision_tower_tunable(golden_dir):
     assert bool(torch.isfinite(eng.lm.flat.float()).all())
 
 
+def _check_slices(eng, g, logits, images):
+    ref = torch.from_numpy(g["logits_slice"])
+    got = logits[:, ::7, ::997]
+    assert float((got - ref).abs().max() / float(g["logits_absmax"].max())) < 3e-2
+
+
+def test_toy_qwen2_siglip(golden_dir):
+    """Qwen2 decoder (GQA 4/2 heads, q/k/v bias, rope theta 1e6, eps 1e-6) over the SigLIP tower (729 tokens,
+    head_dim 24 -> padded heads, gelu_tanh, conv bias, no class token) against the reference's LlavaQwenForCausalLM."""
+    g, meta, images = _golden(golden_dir, "toy_qwen_e2e")
+    eng = _engine("toy_qwen")
+    loss, logits, plan = _run(eng, g, images)
+    _check(eng, g, meta, loss, logits, plan, full=False)
+    _check_slices(eng, g, logits, images)
+    tab = eng.encode_images(torch.stack(images).to("cuda:0").to(torch.bfloat16))
+    ref = torch.from_numpy(g["image_features_slice"]).flatten(0, 1)
+    assert float((tab[:-1, ::37].float().cpu() - ref).abs().max() / ref.abs().max()) < 3e-2
+
+
+def test_toy_qwen2_anyres_max_tower_tunable(golden_dir):
+    """The RadVLM recipe shape (finetune_radio_7b.sh): anyres_max_N + spatial_unpad (bilinear down-sampling of the unpadded
+    grid, llava_arch.py:381-392) with the SigLIP tower tunable -> tower backward through padded heads."""
+    g, meta, images = _golden(golden_dir, "toy_qwen_anyres_max_e2e")
+    eng = _engine("toy_qwen", merge_type=meta["merge_type"], image_aspect_ratio=meta["aspect"], image_grid_pinpoints=meta["pinpoints"],
+                  train_vision_tower=True)
+    sizes = [tuple(s) for s in g["image_sizes"].tolist()]
+    loss, logits, plan = _run(eng, g, images, sizes)
+    assert plan["n_extra_rows"] == 38 * 38
+    _check(eng, g, meta, loss, logits, plan, full=False)
+    _check_slices(eng, g, logits, images)
+    eng.optimizer_step(lr=1e-3, max_grad_norm=1.0, mm_vision_tower_lr=2e-4)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(eng.lm.flat.float()).all())
+
+
 def test_config1(golden_dir):
     g, meta, images = _golden(golden_dir, "config1_e2e")
     eng = _engine("config1")

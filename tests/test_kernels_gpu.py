@@ -215,6 +215,86 @@ def test_attention_fwd_bwd(ops, B, S, H, hd, causal, lens):
             assert float(gg.view(B, S, H, hd).transpose(1, 2).cpu().float()[~vm].abs().max()) == 0.0, name
 
 
+@pytest.mark.parametrize("B,S,H,Hkv,hd,lens", [(2, 200, 4, 2, 64, [200, 77]), (1, 300, 8, 2, 128, None), (2, 70, 6, 1, 128, [70, 33])])
+def test_attention_gqa(ops, B, S, H, Hkv, hd, lens):
+    """Grouped-query attention (Qwen2): query head h reads k/v head h // (H/Hkv); dK/dV sum over the group (repeat_kv adjoint)."""
+    from oracle import llava_oracle as O
+    d, kvd = H * hd, Hkv * hd
+    s_pad = (S + 63) // 64 * 64
+    qkv = rnd(117, (B * S, d + 2 * kvd), 1.0)
+    dout = rnd(118, (B * S, d), 1.0)
+    if lens is not None:
+        for b, L in enumerate(lens):
+            dout.view(B, S, d)[b, L:] = 0
+    hq = lambda t: t.float().view(B, S, H, hd).transpose(1, 2)
+    hk = lambda t: t.float().view(B, S, Hkv, hd).transpose(1, 2)
+    q = hq(qkv[:, :d]).requires_grad_(True)
+    k = hk(qkv[:, d:d + kvd]).requires_grad_(True)
+    v = hk(qkv[:, d + kvd:]).requires_grad_(True)
+    rep = H // Hkv
+    ref = O.attention(q, k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1), lens=lens, causal=True)
+    ref.backward(hq(dout))
+    g = qkv.cuda()
+    gq, gk, gv = g[:, :d], g[:, d:d + kvd], g[:, d + kvd:]
+    vT = ops.transpose_heads(gv, B, S, Hkv, hd, s_pad)
+    lens_t = torch.tensor(lens, dtype=torch.int32, device="cuda") if lens is not None else None
+    out, lse = ops.attn_fwd(gq, gk, vT, B, S, H, hd, s_pad, True, lens=lens_t, kv_heads=Hkv)
+    valid = torch.ones(B, S, dtype=torch.bool)
+    if lens is not None:
+        for b, L in enumerate(lens):
+            valid[b, L:] = False
+    vq = valid[:, None, :, None].expand(B, H, S, hd)
+    vk = valid[:, None, :, None].expand(B, Hkv, S, hd)
+    assert relerr(out.view(B, S, H, hd).transpose(1, 2).cpu().float()[vq], ref.detach()[vq]) < TOL
+    dq, dk, dv = ops.attn_bwd(gq, gk, gv, out, dout.cuda(), lse, B, S, H, hd, s_pad, True, lens=lens_t, kv_heads=Hkv)
+    assert dk.shape == (B * S, kvd) and dv.shape == (B * S, kvd)
+    assert relerr(dq.view(B, S, H, hd).transpose(1, 2).cpu().float()[vq], q.grad[vq]) < 2 * TOL
+    for name, gg, rr in (("dk", dk, k.grad), ("dv", dv, v.grad)):
+        got = gg.view(B, S, Hkv, hd).transpose(1, 2).cpu().float()
+        assert relerr(got[vk], rr[vk]) < 2 * TOL, name
+        if lens is not None:
+            assert float(got[~vk].abs().max()) == 0.0, name
+
+
+def test_gelu_tanh_and_weighted_rows(ops):
+    import torch.nn.functional as F
+    x, dy = rnd(130, (37, 200), 2.0), rnd(131, (37, 200), 1.0)
+    xr = x.float().requires_grad_(True)
+    y = F.gelu(xr, approximate="tanh")
+    y.backward(dy.float())
+    assert relerr(ops.gelu_tanh_fwd(x.cuda()).cpu().float(), y.detach()) < TOL
+    assert relerr(ops.gelu_tanh_bwd(dy.cuda(), x.cuda()).cpu().float(), xr.grad) < TOL
+    # fused in the GEMM epilogue
+    a, w, b = rnd(132, (70, 96), 1.0), rnd(133, (200, 96), 0.2), rnd(134, (200,), 0.5)
+    ref = F.gelu(F.linear(a.float(), w.float(), b.float()), approximate="tanh")
+    got = ops.gemm_nt(a.cuda(), w.cuda(), bias=b.cuda(), act=ops.ACT_GELU_TANH)
+    assert relerr(got.cpu().float(), ref) < TOL
+    # bilinear down-sampling taps == F.interpolate, and the adjoint through the transposed tap list
+    from radvlm_amd.splice import bilinear_taps
+    h, wd, oh, ow, dch = 54, 40, 38, 28, 64
+    src = rnd(135, (h * wd, dch), 1.0)
+    idx, wt = bilinear_taps(h, wd, oh, ow)
+    grid = src.float().view(h, wd, dch).permute(2, 0, 1)[None].requires_grad_(True)
+    want = F.interpolate(grid, [oh, ow], mode="bilinear")
+    gout = rnd(136, (oh * ow, dch), 1.0)
+    want.backward(gout.float().view(oh, ow, dch).permute(2, 0, 1)[None])
+    dev = "cuda"
+    n = oh * ow
+    out = torch.zeros(n, dch, dtype=torch.bfloat16, device=dev)
+    ops.weighted_segment_sum_rows(src.cuda(), torch.arange(0, 4 * n + 1, 4, dtype=torch.int32, device=dev),
+                                  torch.from_numpy(idx.reshape(-1).astype(np.int32)).to(dev), torch.from_numpy(wt.reshape(-1)).to(dev),
+                                  torch.arange(n, dtype=torch.int32, device=dev), out)
+    assert relerr(out.cpu().float(), want[0].permute(1, 2, 0).reshape(n, dch).detach()) < TOL
+    flat = idx.reshape(-1)
+    order = np.argsort(flat, kind="stable")
+    usrc, starts = np.unique(flat[order], return_index=True)
+    off = np.concatenate([starts, [flat.shape[0]]]).astype(np.int32)
+    dsrc = torch.zeros(h * wd, dch, dtype=torch.bfloat16, device=dev)
+    ops.weighted_segment_sum_rows(gout.cuda(), torch.from_numpy(off).to(dev), torch.from_numpy((order // 4).astype(np.int32)).to(dev),
+                                  torch.from_numpy(wt.reshape(-1)[order]).to(dev), torch.from_numpy(usrc.astype(np.int32)).to(dev), dsrc)
+    assert relerr(dsrc.cpu().float(), grid.grad[0].permute(1, 2, 0).reshape(h * wd, dch)) < TOL
+
+
 def test_swiglu_gelu(ops):
     rows, F = 37, 448
     gu, dact = rnd(19, (rows, 2 * F)), rnd(20, (rows, F))
