@@ -34,6 +34,17 @@ def synthetic_batch_anyres(geo, b, seed):
     return ids, mask, labels, images, [(672, 672)] * b
 
 
+def synthetic_batch_radvlm(geo, b, seed):
+    """SURVEY 8f.1 / finetune_radio_7b.sh recipe shape: one 1024x1024 radiograph per sample -> anyres best resolution
+    1152x1152 = 3x3 tiles + the base tile (10 tiles of 384 px), spatial_unpad + anyres_max_9 (81x81 grid = exactly the 9-tile
+    limit, so no down-sampling), 129 ids -> S = 128 + 729 + 81*82 = 7499."""
+    ids, mask, labels, _ = synthetic_batch(geo, b, seed)
+    g = torch.Generator().manual_seed(seed)
+    img = geo["vision"]["image"]
+    images = [torch.randn(10, 3, img, img, generator=g).to(torch.bfloat16) for _ in range(b)]
+    return ids, mask, labels, images, [(1024, 1024)] * b
+
+
 def synthetic_batch(geo, b, seed):
     """SURVEY.md section 8d inputs: ids uniform in [3, V), IMAGE_TOKEN_INDEX at 35, first 64 text positions ignored."""
     V = geo["lm"]["vocab"]
@@ -161,8 +172,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="pairs per GPU per step (global batch 256 at 8 GPUs)")
     ap.add_argument("--geometry", default="llava15_7b")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="cxr", choices=["cxr", "anyres", "lora"],
-                    help="cxr = BASELINE configs 2/3 (headline); anyres = config 4 (S=3056); lora = config 5 (r=64 adapters)")
+    ap.add_argument("--workload", default="cxr", choices=["cxr", "anyres", "lora", "radvlm"],
+                    help="cxr = BASELINE configs 2/3 (headline); anyres = config 4 (S=3056); lora = config 5 (r=64 adapters); "
+                         "radvlm = SURVEY 8f.1 (Qwen2-7B + SigLIP, anyres_max_9, all parts tunable; use --geometry llava_ov_qwen2_7b --batch 2)")
     ap.add_argument("--lr", type=float, default=2e-5)
     args = ap.parse_args()
 
@@ -196,9 +208,13 @@ def main():
                   image_grid_pinpoints=[[336, 672], [672, 336], [672, 672], [1008, 336], [336, 1008]])
     if args.workload == "lora":
         kw = dict(lora=dict(r=64, alpha=16, dropout=0.05))
+    if args.workload == "radvlm":
+        kw = dict(merge_type="spatial_unpad", image_aspect_ratio="anyres_max_9", image_grid_pinpoints="(1x1),...,(6x6)",
+                  train_vision_tower=True)
     eng = LlavaEngine(geo, device=f"cuda:{local}", init="fast", seed=0, process_group=pg, **kw)
     eng.init_optimizer()
-    batch = (synthetic_batch_anyres if args.workload == "anyres" else synthetic_batch)(geo, args.batch, seed=1234 + rank)
+    make = {"anyres": synthetic_batch_anyres, "radvlm": synthetic_batch_radvlm}.get(args.workload, synthetic_batch)
+    batch = make(geo, args.batch, seed=1234 + rank)
 
     def step():
         loss = eng.forward(*batch)
@@ -248,13 +264,16 @@ def main():
         roofline["step_frac_of_mfma_peak"] = roofline["step_algorithmic_tflops"] / PEAK_BF16_TFLOPS
     if rank == 0:
         out = {
-            "metric": "train image-instruction pairs/sec, LLaVA-1.5-7B 336px", "value": value, "unit": "pairs/s",
+            "metric": ("train image-instruction pairs/sec, LLaVA-OV Qwen2-7B + SigLIP-so400m 384px anyres_max_9 (SURVEY 8f.1; not the "
+                       "BASELINE metric)" if args.workload == "radvlm" else "train image-instruction pairs/sec, LLaVA-1.5-7B 336px"),
+            "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.geometry} {'LoRA r=64' if args.workload == 'lora' else 'full fine-tune'} step (ViT frozen): "
-                                   f"fwd+bwd+AdamW, {'anyres 5 tiles, S=3056' if args.workload == 'anyres' else 'S=704'}, "
+            "config": {"workload": f"{args.geometry} {'LoRA r=64' if args.workload == 'lora' else 'full fine-tune'} step "
+                                   f"({'tower tunable' if args.workload == 'radvlm' else 'ViT frozen'}): fwd+bwd+AdamW, "
+                                   f"{ {'anyres': 'anyres 5 tiles, S=3056', 'radvlm': 'anyres_max_9 10 tiles, S=7499'}.get(args.workload, 'S=704')}, "
                                    f"{args.batch} pairs/GPU/step", "global_batch": args.batch * world,
-                       "seq_len": 3056 if args.workload == "anyres" else 704,
+                       "seq_len": {"anyres": 3056, "radvlm": 7499}.get(args.workload, 704),
                        "parallelism": f"dp{world}", "final_loss": final_loss},
             "roofline": roofline,
         }

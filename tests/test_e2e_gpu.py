@@ -329,3 +329,50 @@ def test_full_width_7b_layer_geometry():
         got, want = eng.G(k).float().cpu(), P[k].grad
         rel = float((got - want).norm() / want.norm())
         assert rel < 6e-2, (k, rel)
+
+
+def test_full_width_qwen2_siglip_layer_geometry():
+    """RadVLM's real widths (SURVEY 8f.1: Qwen2-7B d=3584, 28 query / 4 key-value heads x 128, ffn=18944, q/k/v bias;
+    SigLIP-so400m d=1152, 16 heads x 72 -> padded to 128, ffn=4304, 729 tokens at 384 px) at reduced depth (1 decoder layer,
+    2 executed tower layers, vocab 2048), tower tunable, against the CPU oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import llava_oracle as O
+    from radvlm_amd.engine import LlavaEngine
+    geo = {"vision": dict(kind="siglip", d=1152, heads=16, ffn=4304, layers=3, image=384, patch=14),
+           "lm": dict(d=3584, heads=28, kv_heads=4, ffn=18944, layers=1, vocab=2048, qkv_bias=True, rope_theta=1e6, rms_eps=1e-6)}
+    g = torch.Generator().manual_seed(6)
+    B, T = 2, 40
+    ids = torch.randint(3, 2048, (B, T), generator=g)
+    labels = ids.clone()
+    labels[:, :10] = -100
+    ids[:, 7] = -200
+    labels[:, 7] = -100
+    ids[1, 30:] = 0
+    labels[1, 30:] = -100
+    mask = torch.ones(B, T, dtype=torch.bool)
+    mask[1, 30:] = False
+    images = [torch.randn(3, 384, 384, generator=g).to(torch.bfloat16).float() for _ in range(B)]
+    eng = LlavaEngine(geo, device="cuda:0", init="fast", seed=4, train_vision_tower=True)
+    loss = eng.forward(ids.numpy(), mask.numpy(), labels.numpy(), images, want_logits=True)
+    logits = eng.last_logits.cpu()
+    plan_mask = torch.from_numpy(eng.ctx["plan"]["attention_mask"])
+    eng.backward()
+    torch.cuda.synchronize()
+    P = {k: v.float().cpu().requires_grad_(True) for k, v in eng.state_dict().items()}
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    rl, rlog, aux = O.llava_forward(P, geo, ids, mask, labels, images)
+    rl.backward()
+    assert aux["inputs_embeds"].shape[1] == 729 + T - 1
+    assert abs(float(loss) - float(rl)) < 1e-2, (float(loss), float(rl))
+    ref = rlog.detach()[plan_mask]
+    assert float((logits[plan_mask] - ref).abs().max() / ref.abs().max()) < 3e-2
+    vp = "model.vision_tower.vision_tower.vision_model."
+    for k in ("lm_head.weight", "model.layers.0.mlp.down_proj.weight", "model.layers.0.self_attn.q_proj.weight",
+              "model.layers.0.self_attn.k_proj.weight", "model.layers.0.self_attn.v_proj.bias", "model.layers.0.self_attn.o_proj.weight",
+              "model.mm_projector.0.weight", vp + "encoder.layers.0.self_attn.q_proj.weight", vp + "encoder.layers.1.self_attn.out_proj.weight",
+              vp + "encoder.layers.0.mlp.fc1.weight", vp + "encoder.layers.1.mlp.fc2.bias", vp + "embeddings.patch_embedding.weight",
+              vp + "embeddings.patch_embedding.bias", vp + "embeddings.position_embedding.weight"):
+        got, want = eng.G(k).float().cpu(), P[k].grad
+        rel = float((got - want).norm() / want.norm())
+        assert rel < 6e-2, (k, rel)
