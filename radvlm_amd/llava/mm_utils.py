@@ -54,6 +54,34 @@ class ClipImageProcessor:
     __call__ = preprocess
 
 
+class SigLipImageProcessor:
+    """SigLipImageProcessor (multimodal_encoder/siglip_encoder.py:34-67): RGB, direct bicubic resize to `size` (no aspect
+    preservation, no crop), rescale 1/255, normalise with mean = std = 0.5, channels first.  `size` is a (h, w) tuple like
+    the reference's, which process_anyres_image reads as ``processor.size[0]`` (mm_utils.py:257-260)."""
+
+    def __init__(self, image_mean=(0.5, 0.5, 0.5), image_std=(0.5, 0.5, 0.5), size=(384, 384), crop_size=None, rescale_factor=1 / 255):
+        self.image_mean = image_mean
+        self.image_std = image_std
+        self.size = size
+        self.rescale_factor = rescale_factor
+        self.crop_size = crop_size if crop_size is not None else {"height": 384, "width": 384}
+
+    def _one(self, img):
+        img = img.convert("RGB")
+        h, w = self.size
+        img = img.resize((w, h), resample=Image.BICUBIC)
+        a = np.asarray(img).astype(np.float64) * self.rescale_factor
+        a = (a.astype(np.float32) - np.asarray(self.image_mean, dtype=np.float32)) / np.asarray(self.image_std, dtype=np.float32)
+        return torch.from_numpy(a.transpose(2, 0, 1).copy())
+
+    def preprocess(self, images, return_tensors="pt"):
+        if not isinstance(images, (list, tuple)):
+            images = [images]
+        return {"pixel_values": torch.stack([self._one(im) for im in images], 0)}
+
+    __call__ = preprocess
+
+
 def resize_and_pad_image(image, target_resolution):
     """Aspect-preserving resize to fit `target_resolution` (w, h), centred on a black canvas."""
     ow, oh = image.size

@@ -136,6 +136,7 @@ class LlavaLlamaModel:
 
 class LlavaLlamaForCausalLM:
     config_class = LlavaConfig
+    model_class = LlavaLlamaModel
 
     def __init__(self, config, device="cuda", process_group=None, init="portable", seed=0):
         self.config = config
@@ -145,7 +146,7 @@ class LlavaLlamaForCausalLM:
                                   rope_theta=config.rope_theta, process_group=process_group,
                                   train_vision_tower=getattr(config, "unfreeze_mm_vision_tower", False),
                                   lora=getattr(config, "lora", None))
-        self.model = LlavaLlamaModel(self.engine, config)
+        self.model = self.model_class(self.engine, config)
         self.training = True
         # a leaf that makes loss require grad so that `.backward()` reaches the engine
         self._anchor = torch.zeros(1, device=self.engine.device, requires_grad=True)
@@ -177,7 +178,7 @@ class LlavaLlamaForCausalLM:
         from ... import ops
         x = images.to(e.device)
         x = x if x.dtype == torch.bfloat16 else ops.to_bf16(x.float())
-        return e.encode_images(x.contiguous())[:-1].view(x.shape[0], e.P, e.l["d"])
+        return e.encode_images(x.contiguous())[:x.shape[0] * e.P].view(x.shape[0], e.P, e.l["d"])
 
     def initialize_vision_tokenizer(self, model_args, tokenizer):
         """llava_arch.py:557-597: only the no-extra-token configuration of LLaVA-1.5 is on the hot path."""

@@ -257,27 +257,41 @@ def preprocess_plain(sources, tokenizer):
 
 
 def preprocess_qwen(sources, tokenizer, has_image=False, max_len=2048, system_message="You are a helpful assistant."):
-    """ChatML template via the tokenizer's chat template; non-assistant turns masked (train.py:560-633)."""
+    """ChatML supervision of train/train.py:560-633: every turn is rendered as '<|im_start|>{role}\n{content}<|im_end|>\n'
+    (the chat template the reference installs, :579) and tokenised without further special tokens; system and user turns are
+    masked, assistant turns supervised in full (header included); then -- as the reference does (:575, :620-622) -- every
+    token whose id is 198 ('\n' in the Qwen2 vocabulary), <|im_start|> or <|im_end|> is un-masked wherever it occurs, and
+    '<image>' ids become IMAGE_TOKEN_INDEX.  A leading non-human turn is dropped (:592-593)."""
     roles = {"human": "user", "gpt": "assistant"}
     tokenizer = copy.deepcopy(tokenizer)
     if has_image:
         tokenizer.add_tokens(["<image>"], special_tokens=True)
     image_token_index = tokenizer.convert_tokens_to_ids("<image>")
-    unmask = {tokenizer.convert_tokens_to_ids(t) for t in ("<|im_start|>", "<|im_end|>")} | set(tokenizer("\n").input_ids)
-    tokenizer.chat_template = ("{% for message in messages %}{{'<|im_start|>' + message['role'] + '\n' + message['content'] + "
-                               "'<|im_end|>' + '\n'}}{% endfor %}{% if add_generation_prompt %}{{ '<|im_start|>assistant\n' }}{% endif %}")
+    extra = getattr(tokenizer, "additional_special_tokens_ids", None)    # transformers 4.x attribute (:573)
+    if extra is None:
+        extra = tokenizer.convert_tokens_to_ids(["<|im_start|>", "<|im_end|>"])
+    im_start, im_end = extra
+    unmask = (198, im_start, im_end)
+
+    def encode(role, content):
+        return list(tokenizer("<|im_start|>" + role + "\n" + content + "<|im_end|>" + "\n", add_special_tokens=False).input_ids)
+
     all_ids, all_tgt = [], []
     for source in sources:
-        if roles.get(source[0]["from"], source[0]["from"]) != "user":
+        if roles[source[0]["from"]] != roles["human"]:
             source = source[1:]
-        ids = list(tokenizer.apply_chat_template([{"role": "system", "content": system_message}]))
+        ids = encode("system", system_message)
         tgt = [IGNORE_INDEX] * len(ids)
         for conv in source:
-            role = roles.get(conv.get("from", conv.get("role")), conv.get("from", conv.get("role")))
-            enc = tokenizer.apply_chat_template([{"role": role, "content": conv.get("value", conv.get("content"))}])
+            try:
+                role, content = conv["role"], conv["content"]
+            except KeyError:
+                role, content = conv["from"], conv["value"]
+            role = roles.get(role, role)
+            enc = encode(role, content)
             ids += enc
             tgt += [IGNORE_INDEX] * len(enc) if role in ("user", "system") else enc
-        assert len(ids) == len(tgt)
+        assert len(ids) == len(tgt), f"{len(ids)} != {len(tgt)}"
         for i, e in enumerate(ids):
             if e in unmask:
                 tgt[i] = e
@@ -473,7 +487,8 @@ def tunable_parts(model_args):
 
 
 def train(attn_implementation=None, argv=None, tokenizer=None):
-    from ..model import LlavaConfig, LlavaLlamaForCausalLM
+    from ..model import LlavaConfig, LlavaLlamaForCausalLM, LlavaQwenConfig, LlavaQwenForCausalLM
+    from ..mm_utils import SigLipImageProcessor
     from ...config import GEOMETRIES
     model_args, data_args, training_args = parse_args_into_dataclasses(argv)
     world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
@@ -491,12 +506,18 @@ def train(attn_implementation=None, argv=None, tokenizer=None):
         if training_args.lora_bias != "none" or "mm_vision_tower" in parts:
             raise NotImplementedError("lora_bias != 'none' / LoRA together with a tunable vision tower")
         lora = dict(r=training_args.lora_r, alpha=training_args.lora_alpha, dropout=training_args.lora_dropout)
-    name = model_args.geometry or ("llava15_13b" if "13b" in (model_args.model_name_or_path or "").lower() else "llava15_7b")
-    cfg = LlavaConfig(geometry=GEOMETRIES[name], mm_patch_merge_type=model_args.mm_patch_merge_type,
+    mname = (model_args.model_name_or_path or "").lower()
+    # model-class routing of get_model (train/train.py:1366-1436): 'qwen' in the name -> LlavaQwenForCausalLM, else Llama
+    is_qwen = "qwen" in mname or (model_args.geometry or "").find("qwen") >= 0
+    name = model_args.geometry or ("llava_ov_qwen2_7b" if is_qwen else ("llava15_13b" if "13b" in mname else "llava15_7b"))
+    Config, Model = (LlavaQwenConfig, LlavaQwenForCausalLM) if is_qwen else (LlavaConfig, LlavaLlamaForCausalLM)
+    if lora is not None and is_qwen:
+        raise NotImplementedError("LoRA on the Qwen2 decoder (grouped-query k/v, biases) is not built yet")
+    cfg = Config(geometry=GEOMETRIES[name], mm_patch_merge_type=model_args.mm_patch_merge_type,
                       image_aspect_ratio=data_args.image_aspect_ratio, image_grid_pinpoints=data_args.image_grid_pinpoints,
                       tokenizer_model_max_length=training_args.model_max_length,
                       unfreeze_mm_vision_tower="mm_vision_tower" in parts, lora=lora)
-    model = LlavaLlamaForCausalLM(cfg, device=f"cuda:{local}", process_group=pg, init="fast")
+    model = Model(cfg, device=f"cuda:{local}", process_group=pg, init="fast")
     model.config.use_cache = False
     model.get_model().initialize_vision_modules(model_args)
     if model_args.version in conversation_lib.conv_templates:
@@ -507,7 +528,11 @@ def train(attn_implementation=None, argv=None, tokenizer=None):
         import transformers
         tokenizer = transformers.AutoTokenizer.from_pretrained(model_args.model_name_or_path, cache_dir=training_args.cache_dir,
                                                                 model_max_length=training_args.model_max_length, padding_side="right", use_fast=False)
-    data_args.image_processor = ClipImageProcessor(size=cfg.geometry["vision"]["image"])
+    side = cfg.geometry["vision"]["image"]
+    if cfg.geometry["vision"].get("kind") == "siglip":
+        data_args.image_processor = SigLipImageProcessor(size=(side, side), crop_size={"height": side, "width": side})
+    else:
+        data_args.image_processor = ClipImageProcessor(size=side)
     data_args.is_multimodal = True
     data_args.mm_use_im_start_end = model_args.mm_use_im_start_end
     module = make_supervised_data_module(tokenizer=tokenizer, data_args=data_args)

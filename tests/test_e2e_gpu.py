@@ -376,3 +376,63 @@ def test_full_width_qwen2_siglip_layer_geometry():
         got, want = eng.G(k).float().cpu(), P[k].grad
         rel = float((got - want).norm() / want.norm())
         assert rel < 6e-2, (k, rel)
+
+
+def test_qwen_api_surface_and_trainer(golden_dir, tmp_path):
+    """llava.model.LlavaQwenForCausalLM + the RadVLM recipe pieces end to end: ChatML preprocessing (preprocess_qwen), SigLIP
+    image processor, anyres_max tiling, tower tunable, 2 optimizer steps of the trainer on a tiny LLaVA-JSON dataset."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import json as _json
+    import sys
+    from PIL import Image
+    sys.path.insert(0, golden_dir)
+    import toy_chatml_tokenizer as T
+    from radvlm_amd.llava import conversation as conv_lib
+    from radvlm_amd.llava.mm_utils import SigLipImageProcessor
+    from radvlm_amd.llava.model import LlavaQwenConfig, LlavaQwenForCausalLM
+    from radvlm_amd.llava.train.llava_trainer import LLaVATrainer
+    from radvlm_amd.llava.train.train import DataArguments, TrainingArguments, make_supervised_data_module
+    g, meta, images = _golden(golden_dir, "toy_qwen_e2e")
+    pin = [[54, 108], [108, 54], [108, 108]]
+    cfg = LlavaQwenConfig(geometry=GEOMETRIES["toy_qwen"])
+    assert cfg.num_key_value_heads == 2 and cfg.model_type == "llava_qwen"
+    model = LlavaQwenForCausalLM(cfg, device="cuda:0", init="portable")
+    out = model(input_ids=torch.from_numpy(g["input_ids"]), attention_mask=torch.from_numpy(g["attention_mask"]),
+                labels=torch.from_numpy(g["labels"]), images=images, image_sizes=None, modalities=["image"] * 3, output_logits=True)
+    assert abs(float(out.loss) - float(g["loss"])) < 5e-3
+    out.loss.backward()
+    want = meta["grad_norms"]["model.layers.0.self_attn.k_proj.weight"]
+    assert abs(float(model.engine.G("model.layers.0.self_attn.k_proj.weight").float().norm()) - want) < 5e-2 * want
+    tower = model.get_vision_tower()
+    assert tower.num_patches_per_side == 27 and tuple(tower(torch.stack(images)).shape) == (3, 729, 96)
+    model.engine.zero_grad()
+    # the recipe: anyres_max + spatial_unpad, everything tunable
+    cfg2 = LlavaQwenConfig(geometry=GEOMETRIES["toy_qwen"], mm_patch_merge_type="spatial_unpad", image_aspect_ratio="anyres_max_2",
+                           image_grid_pinpoints=pin, unfreeze_mm_vision_tower=True)
+    del model
+    model = LlavaQwenForCausalLM(cfg2, device="cuda:0", init="portable")
+    rng = np.random.default_rng(0)
+    recs = []
+    for i in range(4):
+        Image.fromarray(rng.integers(0, 255, (100, 100 if i % 2 else 60, 3), dtype=np.uint8)).save(tmp_path / f"im{i}.png")
+        recs.append({"id": f"s{i}", "image": f"im{i}.png", "conversations": [{"from": "human", "value": "<image>\nWhat is it?"},
+                                                                            {"from": "gpt", "value": f"Finding number {i}."}]})
+    recs.append({"id": "t", "conversations": [{"from": "human", "value": "Hello there"}, {"from": "gpt", "value": "General reply."}]})
+    (tmp_path / "d.json").write_text(_json.dumps(recs))
+    conv_lib.default_conversation = conv_lib.conv_templates["qwen_2"]
+    try:
+        da = DataArguments(data_path=str(tmp_path / "d.json"), image_folder=str(tmp_path), image_aspect_ratio="anyres_max_2",
+                           image_grid_pinpoints=pin, is_multimodal=True)
+        da.image_processor = SigLipImageProcessor(size=(54, 54), crop_size={"height": 54, "width": 54})
+        da.mm_use_im_start_end = False
+        tok = T.build()
+        tok.model_max_length = 4096
+        module = make_supervised_data_module(tokenizer=tok, data_args=da)
+        item = module["train_dataset"][0]
+        assert item["image"][0][0].shape[1:] == (3, 54, 54) and item["image"][0][0].shape[0] in (3, 5) and -200 in item["input_ids"].tolist()
+        args = TrainingArguments(per_device_train_batch_size=2, gradient_accumulation_steps=1, max_steps=2, learning_rate=1e-3, warmup_ratio=0.0)
+        state = LLaVATrainer(model=model, tokenizer=tok, args=args, **module).train()
+        assert state["global_step"] == 2 and all(np.isfinite(r["loss"]) for r in state["log_history"])
+    finally:
+        conv_lib.default_conversation = conv_lib.conv_templates["v1"]

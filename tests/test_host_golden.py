@@ -215,3 +215,30 @@ def test_arg_parsing_and_tunable_parts():
     assert TR.tunable_parts(m) == {"mm_mlp_adapter", "mm_language_model"}
     m.mm_tunable_parts = "mm_vision_tower,mm_mlp_adapter,mm_language_model"
     assert "mm_vision_tower" in TR.tunable_parts(m)
+
+
+def test_preprocess_qwen_and_siglip_processor(golden_dir):
+    """SURVEY 8f.1 host functions against the reference's outputs (tests/golden/make_golden_host_qwen.py)."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    import toy_chatml_tokenizer as T
+    from radvlm_amd.llava.mm_utils import SigLipImageProcessor
+    H = json.load(open(os.path.join(golden_dir, "host_golden_qwen.json")))
+    A = np.load(os.path.join(golden_dir, "host_images_qwen.npz"))
+    tok = T.build()                                   # plain transformers-5 tokenizer: no 4.x adapter needed on this side
+    k = 0
+    for c in H["conversations"]:
+        for has_image in (True, False):
+            want = H["qwen"][k]
+            k += 1
+            assert want["has_image"] == has_image
+            d = TR.preprocess_qwen([copy.deepcopy(c)], tok, has_image=has_image)
+            assert d["input_ids"][0].tolist() == want["input_ids"]
+            assert d["labels"][0].tolist() == want["labels"]
+    assert -200 in H["qwen"][0]["input_ids"] and -200 not in H["qwen"][1]["input_ids"]
+    proc = SigLipImageProcessor()
+    for i, (w, h) in enumerate([(500, 400), (300, 900), (384, 384)]):
+        px = proc.preprocess(img(i, w, h))["pixel_values"][0]
+        assert list(px.shape) == H["siglip_shapes"][i]
+        assert np.abs(px.numpy()[:, ::8, ::8] - A[f"siglip_pre{i}"]).max() < 1e-5
+        assert np.abs(px.numpy().reshape(3, -1).mean(1) - A[f"siglip_pre{i}_mean"]).max() < 1e-5
