@@ -123,7 +123,10 @@ int rv_attn_bwd(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const 
 
 /* Grouped-query form (Qwen2: language_model/llava_qwen.py:46-58 -> HF Qwen2Attention with num_key_value_heads < heads;
  * repeat_kv modeling_llama.py:201-210): k / v / kT / vT / dk / dv hold H_kv heads, query head h uses key/value head
- * h / (H / H_kv); the dK/dV pass sums the group's query heads in registers (no expanded copies).  H % H_kv == 0. */
+ * h / (H / H_kv); the dK/dV pass sums the group's query heads in registers (no expanded copies).  H % H_kv == 0.
+ * Optional `workspace` (>= 2*B*S*H*hd*2 bytes, 16-byte aligned; may be NULL): when the dK/dV grid (key blocks x H_kv x B)
+ * is too small to balance a long causal sequence over the chip, the pass runs one block per QUERY head into the
+ * workspace and a deterministic group sum folds the partials. */
 int rv_attn_fwd_gqa(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* vT, void* out, int64_t ld_o,
                     float* lse, const int32_t* lens, int B, int H, int H_kv, int S, int S_pad, int hd, int causal,
                     float scale, const void* zeros16, void* stream);
@@ -131,7 +134,7 @@ int rv_attn_bwd_gqa(const void* q, int64_t ld_q, const void* k, int64_t ld_k, co
                     int64_t ld_o, const void* dout, int64_t ld_do, const void* qT, const void* kT, const void* doT,
                     const float* lse, float* delta, void* dq, int64_t ld_dq, void* dk, int64_t ld_dk, void* dv,
                     int64_t ld_dv, const int32_t* lens, int B, int H, int H_kv, int S, int S_pad, int hd, int causal,
-                    float scale, const void* zeros16, void* stream);
+                    float scale, void* workspace, int64_t workspace_bytes, const void* zeros16, void* stream);
 
 /* ---- MLP activations ------------------------------------------------------------------------------------------------
  * LlamaMLP (modeling_llama.py:226): act[r, f] = silu(gu[r, f]) * gu[r, F + f]   (gu = fused gate|up output). */

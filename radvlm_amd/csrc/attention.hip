@@ -26,6 +26,7 @@ struct AttnParams {
     const bf16* zeros;
     long ld_q, ld_k, ld_v, ld_o, ld_do, ld_dq, ld_dk, ld_dv;
     int B, H, S, S_pad;
+    int kdiv, qrep;  // dK/dV pass: block head h reads k/v head h / kdiv and walks query heads [h*qrep, (h+1)*qrep)
     int Hkv, nrep;   // grouped-query attention: query head h reads key/value head h / nrep (repeat_kv, modeling_llama.py:201-210)
     float scale;
 };
@@ -333,18 +334,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dkv_kernel(AttnParam
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
         const int row = min(k0 + kb * 16 + c, S - 1);
-        const bf16* kp = P.k + (long)(b * S + row) * P.ld_k + h * HD + g * 8;
-        const bf16* vp = P.v + (long)(b * S + row) * P.ld_v + h * HD + g * 8;
+        const bf16* kp = P.k + (long)(b * S + row) * P.ld_k + (h / P.kdiv) * HD + g * 8;
+        const bf16* vp = P.v + (long)(b * S + row) * P.ld_v + (h / P.kdiv) * HD + g * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) { kf[kb][ks] = *(const bf16x8*)(kp + ks * 32); vf[kb][ks] = *(const bf16x8*)(vp + ks * 32); }
     }
     const int q_end = len;  // query rows >= len carry zero dO
     const int t0 = CAUSAL ? (kblk * KPB) >> 6 : 0;
     const int t1 = (q_end + 63) >> 6;
-    // blockIdx.y is the KEY/VALUE head; its nrep query heads are walked by one flattened (head, query tile) loop so that
-    // dK/dV accumulate in registers across the group and the double-buffered prefetch runs across head boundaries
+    // grouped-query attention, two launch shapes:
+    //  (kdiv 1, qrep n): blockIdx.y is the KEY/VALUE head; its n query heads are walked by one flattened (head, query tile)
+    //    loop, so dK/dV accumulate in registers across the group and the prefetch runs across head boundaries;
+    //  (kdiv n, qrep 1): blockIdx.y is a QUERY head writing per-query-head partials that group_sum_heads_kernel folds --
+    //    n times more blocks, for grids too small to balance the causal triangle over 256 CUs.
     const int nt = max(t1 - t0, 0);
-    const int n_it = nt * P.nrep;
+    const int n_it = nt * P.qrep;
 
     f32x4 dv[DB][NKB], dk[DB][NKB];
 #pragma unroll
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dkv_kernel(AttnParam
         for (int kb = 0; kb < NKB; ++kb) { dv[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[db][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     auto stage = [&](int it, char* dst) {
-        const int hq = h * P.nrep + it / nt;
+        const int hq = h * P.qrep + it / nt;
         const int qt0 = (t0 + it % nt) * 64;
         const bf16* qbase = P.q + (long)b * S * P.ld_q + hq * HD;
         const bf16* dobase = P.dout + (long)b * S * P.ld_do + hq * HD;
@@ -458,6 +462,25 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dkv_kernel(AttnParam
     }
 }
 
+// out[m, hk*HD + e] = sum_r tmp[m, (hk*nrep + r)*HD + e]  (fp32 sum of the group's per-query-head dK or dV partials)
+__global__ void group_sum_heads_kernel(const bf16* tmp, long ld_tmp, bf16* out, long ld_out, long rows, int Hkv, int nrep, int hd) {
+    const int per_row = Hkv * hd / 8;
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= rows * per_row) return;
+    const long m = tid / per_row;
+    const int col = (tid % per_row) * 8, hk = col / hd, e = col % hd;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < nrep; ++r) {
+        const bf16x8 v = *(const bf16x8*)(tmp + m * ld_tmp + (long)(hk * nrep + r) * hd + e);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += (float)v[i];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (__bf16)acc[i];
+    *(bf16x8*)(out + m * ld_out + col) = o;
+}
+
 template <typename K>
 int set_smem(K kern, int bytes) {
     return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 0 : -1;
@@ -500,7 +523,8 @@ extern "C" int rv_attn_bwd_gqa(const void* q, int64_t ld_q, const void* k, int64
                                const void* o, int64_t ld_o, const void* dout, int64_t ld_do, const void* qT, const void* kT,
                                const void* doT, const float* lse, float* delta, void* dq, int64_t ld_dq, void* dk,
                                int64_t ld_dk, void* dv, int64_t ld_dv, const int32_t* lens, int B, int H, int H_kv, int S,
-                               int S_pad, int HD, int causal, float scale, const void* zeros16, void* stream) {
+                               int S_pad, int HD, int causal, float scale, void* workspace, int64_t workspace_bytes,
+                               const void* zeros16, void* stream) {
     if (!q || !k || !v || !o || !dout || !qT || !kT || !doT || !lse || !delta || !dq || !dk || !dv || !zeros16) return RV_ERR_ARG;
     if (H_kv <= 0 || H <= 0 || H % H_kv) return RV_ERR_ARG;
     if ((HD != 64 && HD != 128) || (S_pad & 63) || S_pad < S || B <= 0 || H <= 0 || S <= 0) return RV_ERR_ARG;
@@ -517,6 +541,18 @@ extern "C" int rv_attn_bwd_gqa(const void* q, int64_t ld_q, const void* k, int64
     // 8 waves per block (2 per SIMD): dQ pass = 256 query rows per block, dK/dV pass = 128 keys per block (16 per wave)
     // and one block per KEY/VALUE head (it walks the head's H / H_kv query heads)
     dim3 grid_dq((S + 255) / 256, H, B), grid_dkv((S + 127) / 128, H_kv, B);
+    AttnParams PK = P;        // parameters of the dK/dV pass
+    PK.kdiv = 1; PK.qrep = P.nrep;
+    // few key/value heads and a long causal sequence: per-query-head blocks + a group sum balance better than per-group blocks
+    const int64_t need = 2 * (int64_t)B * S * H * HD * 2;
+    const bool expand = P.nrep > 1 && workspace && workspace_bytes >= need && (((uintptr_t)workspace) & 15) == 0 &&
+                        (long)grid_dkv.x * H_kv * B < 2048;
+    if (expand) {
+        PK.kdiv = P.nrep; PK.qrep = 1;
+        PK.dk = (bf16*)workspace; PK.dv = (bf16*)workspace + (int64_t)B * S * H * HD;
+        PK.ld_dk = PK.ld_dv = (long)H * HD;
+        grid_dkv.y = H;
+    }
     const int smem_dq = 2 * (2 * 64 * HD * 2 + HD * 128);
     const int smem_dkv = 2 * (2 * 64 * HD * 2 + 2 * HD * 128 + 1024);
 #define LAUNCH_BWD(HD_, C_)                                                                                    \
@@ -524,11 +560,16 @@ extern "C" int rv_attn_bwd_gqa(const void* q, int64_t ld_q, const void* k, int64
         set_smem(attn_bwd_dq_kernel<HD_, C_, 8>, smem_dq);                                                     \
         set_smem(attn_bwd_dkv_kernel<HD_, C_, 8, 1>, smem_dkv);                                                \
         hipLaunchKernelGGL((attn_bwd_dq_kernel<HD_, C_, 8>), grid_dq, dim3(512), smem_dq, st, P);              \
-        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD_, C_, 8, 1>), grid_dkv, dim3(512), smem_dkv, st, P);        \
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<HD_, C_, 8, 1>), grid_dkv, dim3(512), smem_dkv, st, PK);       \
     } while (0)
     if (HD == 128) { if (causal) LAUNCH_BWD(128, true); else LAUNCH_BWD(128, false); }
     else { if (causal) LAUNCH_BWD(64, true); else LAUNCH_BWD(64, false); }
 #undef LAUNCH_BWD
+    if (expand) {
+        const long rows = (long)B * S, total = rows * (H_kv * HD / 8);
+        hipLaunchKernelGGL(group_sum_heads_kernel, dim3((total + 255) / 256), dim3(256), 0, st, PK.dk, PK.ld_dk, P.dk, P.ld_dk, rows, H_kv, P.nrep, HD);
+        hipLaunchKernelGGL(group_sum_heads_kernel, dim3((total + 255) / 256), dim3(256), 0, st, PK.dv, PK.ld_dv, P.dv, P.ld_dv, rows, H_kv, P.nrep, HD);
+    }
     return rv_check_launch();
 }
 
@@ -538,5 +579,5 @@ extern "C" int rv_attn_bwd(const void* q, int64_t ld_q, const void* k, int64_t l
                            int64_t ld_dk, void* dv, int64_t ld_dv, const int32_t* lens, int B, int H, int S, int S_pad,
                            int HD, int causal, float scale, const void* zeros16, void* stream) {
     return rv_attn_bwd_gqa(q, ld_q, k, ld_k, v, ld_v, o, ld_o, dout, ld_do, qT, kT, doT, lse, delta, dq, ld_dq, dk, ld_dk, dv, ld_dv,
-                           lens, B, H, H, S, S_pad, HD, causal, scale, zeros16, stream);
+                           lens, B, H, H, S, S_pad, HD, causal, scale, nullptr, 0, zeros16, stream);
 }

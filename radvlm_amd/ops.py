@@ -247,7 +247,7 @@ def attn_fwd(q, k, vT, B, S, H, hd, s_pad, causal, lens=None, scale=None, out=No
 
 
 def attn_bwd(q, k, v, o, dout, lse, B, S, H, hd, s_pad, causal, lens=None, scale=None, dq=None, dk=None, dv=None,
-             kv_heads=None):
+             kv_heads=None, use_workspace=True):
     scale = scale if scale is not None else 1.0 / math.sqrt(hd)
     dev = q.device
     Hkv = kv_heads or H
@@ -258,9 +258,11 @@ def attn_bwd(q, k, v, o, dout, lse, B, S, H, hd, s_pad, causal, lens=None, scale
     dq = torch.empty(B * S, H * hd, dtype=BF16, device=dev) if dq is None else dq
     dk = torch.empty(B * S, Hkv * hd, dtype=BF16, device=dev) if dk is None else dk
     dv = torch.empty(B * S, Hkv * hd, dtype=BF16, device=dev) if dv is None else dv
+    # per-query-head dK/dV partials for the small-grid grouped-query case (the C side decides whether to use it)
+    ws = torch.empty(2 * B * S * H * hd, dtype=BF16, device=dev) if (Hkv != H and use_workspace) else None
     lib.call("rv_attn_bwd_gqa", q, q.stride(0), k, k.stride(0), v, v.stride(0), o, o.stride(0), dout, dout.stride(0), qT, kT, doT,
              lse, delta, dq, dq.stride(0), dk, dk.stride(0), dv, dv.stride(0), lens, B, H, Hkv, S, s_pad, hd, int(causal), scale,
-             lib.zeros16(dev))
+             ws, ws.numel() * ws.element_size() if ws is not None else 0, lib.zeros16(dev))
     return dq, dk, dv
 
 

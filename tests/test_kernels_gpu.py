@@ -246,14 +246,17 @@ def test_attention_gqa(ops, B, S, H, Hkv, hd, lens):
     vq = valid[:, None, :, None].expand(B, H, S, hd)
     vk = valid[:, None, :, None].expand(B, Hkv, S, hd)
     assert relerr(out.view(B, S, H, hd).transpose(1, 2).cpu().float()[vq], ref.detach()[vq]) < TOL
-    dq, dk, dv = ops.attn_bwd(gq, gk, gv, out, dout.cuda(), lse, B, S, H, hd, s_pad, True, lens=lens_t, kv_heads=Hkv)
-    assert dk.shape == (B * S, kvd) and dv.shape == (B * S, kvd)
-    assert relerr(dq.view(B, S, H, hd).transpose(1, 2).cpu().float()[vq], q.grad[vq]) < 2 * TOL
-    for name, gg, rr in (("dk", dk, k.grad), ("dv", dv, v.grad)):
-        got = gg.view(B, S, Hkv, hd).transpose(1, 2).cpu().float()
-        assert relerr(got[vk], rr[vk]) < 2 * TOL, name
-        if lens is not None:
-            assert float(got[~vk].abs().max()) == 0.0, name
+    # both dK/dV launch shapes: per-group blocks (register accumulation) and per-query-head blocks + group sum (workspace)
+    for use_ws in (False, True):
+        dq, dk, dv = ops.attn_bwd(gq, gk, gv, out, dout.cuda(), lse, B, S, H, hd, s_pad, True, lens=lens_t, kv_heads=Hkv,
+                                  use_workspace=use_ws)
+        assert dk.shape == (B * S, kvd) and dv.shape == (B * S, kvd)
+        assert relerr(dq.view(B, S, H, hd).transpose(1, 2).cpu().float()[vq], q.grad[vq]) < 2 * TOL
+        for name, gg, rr in (("dk", dk, k.grad), ("dv", dv, v.grad)):
+            got = gg.view(B, S, Hkv, hd).transpose(1, 2).cpu().float()
+            assert relerr(got[vk], rr[vk]) < 2 * TOL, (name, use_ws)
+            if lens is not None:
+                assert float(got[~vk].abs().max()) == 0.0, (name, use_ws)
 
 
 def test_gelu_tanh_and_weighted_rows(ops):
