@@ -12,7 +12,7 @@ for k in ("A", "B"):
     libs[k] = l
 z = torch.zeros(64, dtype=torch.uint8, device="cuda")
 T = 22528
-CASES = [("qkv_fwd", T, 12288, 4096, 0, 0), ("o_fwd", T, 4096, 4096, 0, 0), ("gu_fwd", T, 22016, 4096, 0, 0), ("down_fwd", T, 4096, 11008, 0, 0),
+CASES = [("sq4096", 4096, 4096, 4096, 0, 0), ("sq8192", 8192, 8192, 8192, 0, 0), ("qkv_fwd", T, 12288, 4096, 0, 0), ("o_fwd", T, 4096, 4096, 0, 0), ("gu_fwd", T, 22016, 4096, 0, 0), ("down_fwd", T, 4096, 11008, 0, 0),
          ("dh2 NN", T, 4096, 22016, 0, 1), ("gu_wgrad TT", 22016, 4096, T, 1, 1), ("o_wgrad TT", 4096, 4096, T, 1, 1), ("vit_fc1", 18464, 4096, 1024, 0, 0),
          ("vit_out", 18464, 1024, 1024, 0, 0)]
 st = torch.cuda.current_stream().cuda_stream
@@ -23,6 +23,11 @@ for name, m, n, k, ta, tb in CASES:
     def run(l):
         rc = l.rv_gemm_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), n, None, None, 0, m, n, k, ta, tb, 1.0, 0, 0, 0, z.data_ptr(), st)
         assert rc == 0
+    # the two builds must agree bit for bit (same accumulation order), also under repetition (race screen)
+    run(libs["A"]); ref = c.clone()
+    for _ in range(6):
+        c.zero_(); run(libs["B"])
+        assert torch.equal(c, ref), f"{name}: B differs from A"
     best = {"A": 1e9, "B": 1e9}
     for rnd in range(4):
         for key in ("A", "B"):
