@@ -258,6 +258,12 @@ def main():
         roofline["traffic_source"] = "profiles/r01_pmc_gemm_hbm_traffic.json (separate --pmc passes of this command)"
     except OSError:
         pass
+    try:  # MFMA-pipe busy fraction and held clock of the GEMM launches (separate rocprofv3 --pmc pass, tools/pmc_mfma_summary.py)
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_mfma_util.json")) as f:
+            if args.workload == "cxr" and args.batch == 32:
+                roofline["pmc_mfma"] = json.load(f)["gemm_kernel_256_all_forms"]
+    except OSError:
+        pass
     tf_pair = TF_PER_PAIR.get(args.geometry) if args.workload == "cxr" else None
     if tf_pair:
         roofline["step_algorithmic_tflops"] = tf_pair * args.batch / (ms_per_step * 1e-3)
