@@ -8,7 +8,11 @@ _get_train_sampler :273-317 (note: world_size * gradient_accumulation_steps, :28
 The loop body the reference inherits from HF Trainer + accelerate + DeepSpeed is replaced by the engine's own step.
 """
 import math
+import os
+import queue
+import threading
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import torch
 from torch.utils.data import Sampler
@@ -146,6 +150,77 @@ def cosine_lr(step, total_steps, base_lr, warmup_steps):
     return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * p)))
 
 
+class BatchPrefetcher:
+    """Host input pipeline that keeps ahead of the GPU step (the reference's torch DataLoader with
+    ``dataloader_num_workers`` workers, scripts: 4).  ``num_workers`` threads run ``dataset[i]`` (PIL decode / resize /
+    anyres tiling release the GIL) for up to ``depth`` batches ahead of the consumer; a feeder thread collates each batch
+    in order and pins its image tensors so the engine's host-to-device copies are asynchronous.  With num_workers = 0 it
+    degenerates to the synchronous loop.  Sample order and contents are exactly those of the synchronous loop."""
+
+    def __init__(self, dataset, collate, index_batches, num_workers=4, depth=3, pin=None):
+        self.dataset, self.collate = dataset, collate
+        self.batches = iter(index_batches)
+        self.pin = torch.cuda.is_available() if pin is None else pin
+        self.sync = num_workers <= 0
+        if not self.sync:
+            self.pool = ThreadPoolExecutor(max_workers=num_workers, thread_name_prefix="rv-data")
+            self.q = queue.Queue(maxsize=max(1, depth))
+            self.stop = threading.Event()
+            self.feeder = threading.Thread(target=self._feed, name="rv-data-feeder", daemon=True)
+            self.feeder.start()
+
+    def _finish(self, samples):
+        batch = self.collate(samples)
+        if self.pin and "images" in batch:
+            batch["images"] = [im.pin_memory() if torch.is_tensor(im) and not im.is_pinned() else im for im in batch["images"]]
+        return batch
+
+    def _feed(self):
+        try:
+            pending = []
+            for idx in self.batches:
+                if self.stop.is_set():
+                    return
+                pending.append([self.pool.submit(self.dataset.__getitem__, i) for i in idx])
+                while len(pending) > self.q.maxsize:       # keep `depth` batches of samples in flight beyond the queue
+                    self._put(self._finish([f.result() for f in pending.pop(0)]))
+            for futs in pending:
+                self._put(self._finish([f.result() for f in futs]))
+            self._put(None)
+        except BaseException as e:  # noqa: BLE001 -- surfaced to the consumer
+            self._put(e)
+
+    def _put(self, item):
+        while not self.stop.is_set():
+            try:
+                self.q.put(item, timeout=0.2)
+                return
+            except queue.Full:
+                continue
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self.sync:
+            return self._finish([self.dataset[i] for i in next(self.batches)])
+        item = self.q.get()
+        if item is None:
+            raise StopIteration
+        if isinstance(item, BaseException):
+            raise item
+        return item
+
+    def close(self):
+        """Stop early or clean up at the end: queued samples are cancelled, running ones finish, both threads are joined
+        (a worker still alive at interpreter exit aborts the process)."""
+        if self.sync:
+            return
+        self.stop.set()
+        self.pool.shutdown(wait=True, cancel_futures=True)
+        self.feeder.join(timeout=10)
+
+
 class LLaVATrainer:
     """Minimal trainer over LlavaEngine with the reference trainer's constructor shape
     (model, tokenizer, args, train_dataset, data_collator) and .train()."""
@@ -184,28 +259,95 @@ class LLaVATrainer:
         steps_per_epoch = len(mine) // (bs * accum)
         total = int(getattr(a, "max_steps", -1)) if getattr(a, "max_steps", -1) > 0 else int(steps_per_epoch * a.num_train_epochs)
         warm = int(getattr(a, "warmup_steps", 0) or total * getattr(a, "warmup_ratio", 0.0))
-        pos = 0
-        for step in range(1, total + 1):
-            t0 = time.perf_counter()
-            losses = []
-            for micro in range(accum):
-                idx = mine[pos:pos + bs]
+        def index_batches():
+            pos = 0
+            for _ in range(total * accum):
+                yield mine[pos:pos + bs]
                 pos = (pos + bs) % max(1, len(mine) - bs + 1)
-                batch = self.data_collator([self.train_dataset[i] for i in idx])
-                eng.sync_this_backward = micro == accum - 1
-                out = self.model(**batch)
-                out.loss.backward()
-                losses.append(out.loss)
-            lr = cosine_lr(step, total, a.learning_rate, warm)
-            eng.optimizer_step(lr=lr, weight_decay=a.weight_decay, betas=(getattr(a, "adam_beta1", 0.9), getattr(a, "adam_beta2", 0.999)),
-                               eps=getattr(a, "adam_epsilon", 1e-8), max_grad_norm=getattr(a, "max_grad_norm", 1.0),
-                               mm_projector_lr=getattr(a, "mm_projector_lr", None),
-                               mm_vision_tower_lr=getattr(a, "mm_vision_tower_lr", None))
-            self.state["global_step"] = step
-            if step % max(1, getattr(a, "logging_steps", 1)) == 0:
-                rec = {"step": step, "loss": float(sum(float(l) for l in losses) / len(losses)), "learning_rate": lr,
-                       "step_time_s": time.perf_counter() - t0}
-                self.state["log_history"].append(rec)
-                if rank == 0:
-                    print(rec, flush=True)
+
+        start = self._maybe_resume(resume_from_checkpoint)
+        it = index_batches()
+        for _ in range(start * accum):       # a resumed run continues the same sample stream
+            next(it)
+        loader = BatchPrefetcher(self.train_dataset, self.data_collator, it, num_workers=int(getattr(a, "dataloader_num_workers", 0) or 0))
+        save_steps = int(getattr(a, "save_steps", 0) or 0)
+        try:
+            for step in range(start + 1, total + 1):
+                t0 = time.perf_counter()
+                losses = []
+                t_data = 0.0
+                for micro in range(accum):
+                    td = time.perf_counter()
+                    batch = next(loader)
+                    t_data += time.perf_counter() - td
+                    eng.sync_this_backward = micro == accum - 1
+                    out = self.model(**batch)
+                    out.loss.backward()
+                    losses.append(out.loss)
+                lr = cosine_lr(step, total, a.learning_rate, warm)
+                eng.optimizer_step(lr=lr, weight_decay=a.weight_decay, betas=(getattr(a, "adam_beta1", 0.9), getattr(a, "adam_beta2", 0.999)),
+                                   eps=getattr(a, "adam_epsilon", 1e-8), max_grad_norm=getattr(a, "max_grad_norm", 1.0),
+                                   mm_projector_lr=getattr(a, "mm_projector_lr", None),
+                                   mm_vision_tower_lr=getattr(a, "mm_vision_tower_lr", None))
+                self.state["global_step"] = step
+                if step % max(1, getattr(a, "logging_steps", 1)) == 0:
+                    rec = {"step": step, "loss": float(sum(float(l) for l in losses) / len(losses)), "learning_rate": lr,
+                           "step_time_s": time.perf_counter() - t0, "data_wait_s": t_data}
+                    self.state["log_history"].append(rec)
+                    if rank == 0:
+                        print(rec, flush=True)
+                if save_steps and step % save_steps == 0 and getattr(a, "output_dir", None):
+                    self.save_checkpoint(os.path.join(a.output_dir, f"checkpoint-{step}"), rank)
+        finally:
+            loader.close()
         return self.state
+
+    # ------------------------------------------------------------------ checkpoints
+    def save_checkpoint(self, path, rank=0):
+        """checkpoint-N directory with what a resumed run needs (train.py:1699-1702 auto-resume looks for checkpoint-*):
+        weights in the reference's state-dict names (safetensors), the adapter-only file of projector-only runs
+        (llava_trainer.py:435-457 writes mm_projector.bin with the keys matched by 'mm_projector'), fp32 master + AdamW moments
+        and the trainer state.  Written by rank 0 only (replicas are identical under data parallelism)."""
+        if rank != 0:
+            return
+        import json
+        from safetensors.torch import save_file
+        eng = self.model.engine
+        os.makedirs(path, exist_ok=True)
+        self.model.save_pretrained(path)
+        proj = {k: v.detach().clone().cpu() for k, v in eng.state_dict().items() if "mm_projector" in k}
+        torch.save(proj, os.path.join(path, "mm_projector.bin"))
+        if eng.master is not None:
+            save_file({"master": eng.master.detach().cpu(), "exp_avg": eng.m.detach().cpu(), "exp_avg_sq": eng.vv.detach().cpu()},
+                      os.path.join(path, "optimizer.safetensors"))
+        with open(os.path.join(path, "trainer_state.json"), "w") as f:
+            json.dump({"global_step": self.state["global_step"], "opt_step": eng.opt_step, "log_history": self.state["log_history"]}, f)
+
+    def _maybe_resume(self, resume_from_checkpoint):
+        """True -> newest checkpoint-* under output_dir (the reference's auto-resume, train.py:1699-1702); str -> that directory."""
+        a = self.args
+        path = resume_from_checkpoint
+        if path is True:
+            root = getattr(a, "output_dir", None)
+            cands = [d for d in (os.listdir(root) if root and os.path.isdir(root) else []) if d.startswith("checkpoint-") and d[11:].isdigit()]
+            path = os.path.join(root, max(cands, key=lambda d: int(d[11:]))) if cands else None
+        if not path:
+            return 0
+        import json
+        from safetensors.torch import load_file
+        eng = self.model.engine
+        name = "model.safetensors" if not eng.lora else None
+        if name is None:
+            raise NotImplementedError("resume of LoRA runs")
+        eng.load_state_dict(load_file(os.path.join(path, name)))
+        opt = os.path.join(path, "optimizer.safetensors")
+        if os.path.exists(opt):
+            eng.init_optimizer()
+            st = load_file(opt)
+            eng.master.copy_(st["master"]), eng.m.copy_(st["exp_avg"]), eng.vv.copy_(st["exp_avg_sq"])
+        with open(os.path.join(path, "trainer_state.json")) as f:
+            ts = json.load(f)
+        eng.opt_step = ts["opt_step"]
+        self.state["global_step"] = ts["global_step"]
+        self.state["log_history"] = ts["log_history"]
+        return ts["global_step"]

@@ -537,7 +537,10 @@ def train(attn_implementation=None, argv=None, tokenizer=None):
     data_args.mm_use_im_start_end = model_args.mm_use_im_start_end
     module = make_supervised_data_module(tokenizer=tokenizer, data_args=data_args)
     trainer = LLaVATrainer(model=model, tokenizer=tokenizer, args=training_args, **module)
-    state = trainer.train()
+    # auto-resume like the reference (train/train.py:1699-1702): continue from the newest checkpoint-* of output_dir
+    has_ckpt = bool(training_args.output_dir) and os.path.isdir(training_args.output_dir) and any(
+        d.startswith("checkpoint-") for d in os.listdir(training_args.output_dir))
+    state = trainer.train(resume_from_checkpoint=True if has_ckpt else None)
     if rank == 0 and training_args.output_dir:
         os.makedirs(training_args.output_dir, exist_ok=True)
         model.save_pretrained(training_args.output_dir)

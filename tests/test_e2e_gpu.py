@@ -436,3 +436,69 @@ def test_qwen_api_surface_and_trainer(golden_dir, tmp_path):
         assert state["global_step"] == 2 and all(np.isfinite(r["loss"]) for r in state["log_history"])
     finally:
         conv_lib.default_conversation = conv_lib.conv_templates["v1"]
+
+
+def test_checkpoint_resume_is_bit_identical(golden_dir, tmp_path):
+    """a run of 4 steps == 2 steps + checkpoint + a fresh process-like resume + 2 steps (weights, fp32 master, AdamW
+    moments, step counters and the sample stream all continue), and the checkpoint holds the reference-format pieces."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import json as _json
+    from PIL import Image
+    from radvlm_amd.llava import conversation as conv_lib
+    from radvlm_amd.llava.mm_utils import ClipImageProcessor
+    from radvlm_amd.llava.model import LlavaConfig, LlavaLlamaForCausalLM
+    from radvlm_amd.llava.train.llava_trainer import LLaVATrainer
+    from radvlm_amd.llava.train.train import DataArguments, TrainingArguments, make_supervised_data_module
+
+    class Ids:
+        def __init__(self, ids):
+            self.input_ids = ids
+
+    class Tok:
+        bos_token_id, pad_token_id, model_max_length, legacy, padding_side = 1, 0, 256, True, "right"
+
+        def __call__(self, s, **kw):
+            ids = [1]
+            for k, piece in enumerate(s.split("</s>")):
+                if k:
+                    ids.append(2)
+                ids.extend(3 + (ord(c) % 900) for c in piece)
+            return Ids(ids)
+
+    rng = np.random.default_rng(1)
+    recs = []
+    for i in range(8):
+        Image.fromarray(rng.integers(0, 255, (64, 80, 3), dtype=np.uint8)).save(tmp_path / f"im{i}.png")
+        recs.append({"id": f"s{i}", "image": f"im{i}.png", "conversations": [{"from": "human", "value": "<image>\nWhat is it?"},
+                                                                            {"from": "gpt", "value": f"Finding number {i} " + "x" * i}]})
+    (tmp_path / "d.json").write_text(_json.dumps(recs))
+    conv_lib.default_conversation = conv_lib.conv_templates["v1"]
+
+    def run(out_dir, max_steps, save_steps, resume):
+        da = DataArguments(data_path=str(tmp_path / "d.json"), image_folder=str(tmp_path), image_aspect_ratio="pad", is_multimodal=True)
+        da.image_processor = ClipImageProcessor(56)
+        da.mm_use_im_start_end = False
+        tok = Tok()
+        model = LlavaLlamaForCausalLM(LlavaConfig(geometry=GEOMETRIES["toy"]), device="cuda:0", init="portable")
+        module = make_supervised_data_module(tokenizer=tok, data_args=da)
+        args = TrainingArguments(per_device_train_batch_size=2, gradient_accumulation_steps=1, max_steps=max_steps, learning_rate=1e-3,
+                                 warmup_ratio=0.0, output_dir=str(out_dir), save_steps=save_steps)
+        tr = LLaVATrainer(model=model, tokenizer=tok, args=args, **module)
+        state = tr.train(resume_from_checkpoint=resume)
+        torch.cuda.synchronize()
+        return model, state
+
+    full, s_full = run(tmp_path / "a", 4, 2, None)          # 4 steps, checkpoints after steps 2 and 4
+    ck = tmp_path / "a" / "checkpoint-2"
+    assert sorted(os.listdir(ck)) == ["mm_projector.bin", "model.safetensors", "optimizer.safetensors", "trainer_state.json"]
+    proj = torch.load(ck / "mm_projector.bin", map_location="cpu", weights_only=True)
+    assert sorted(proj) == ["model.mm_projector.0.bias", "model.mm_projector.0.weight", "model.mm_projector.2.bias", "model.mm_projector.2.weight"]
+    resumed, s_res = run(tmp_path / "b", 4, 0, str(ck))     # fresh model, continue from step 2 of the same 4-step schedule
+    assert s_res["global_step"] == 4 and [r["step"] for r in s_res["log_history"]] == [1, 2, 3, 4]
+    assert torch.equal(resumed.engine.lm.flat, full.engine.lm.flat)
+    assert torch.equal(resumed.engine.master, full.engine.master) and torch.equal(resumed.engine.vv, full.engine.vv)
+    assert [r["loss"] for r in s_res["log_history"]] == [r["loss"] for r in s_full["log_history"]]
+    # auto-resume picks the newest checkpoint: nothing left to do after checkpoint-4
+    again, s_again = run(tmp_path / "a", 4, 0, True)
+    assert s_again["global_step"] == 4 and torch.equal(again.engine.lm.flat, full.engine.lm.flat)
