@@ -45,17 +45,24 @@ def synthetic_batch_radvlm(geo, b, seed):
     return ids, mask, labels, images, [(1024, 1024)] * b
 
 
-def synthetic_batch(geo, b, seed):
-    """SURVEY.md section 8d inputs: ids uniform in [3, V), IMAGE_TOKEN_INDEX at 35, first 64 text positions ignored."""
+def synthetic_batch(geo, b, seed, text_lens=None):
+    """SURVEY.md section 8d inputs: ids uniform in [3, V), IMAGE_TOKEN_INDEX at 35, first 64 text positions ignored.
+    text_lens=(lo, hi): per-sample id counts uniform in [lo, hi] (right padded) instead of the fixed 129 -- the
+    variable-length case that packed batches are for (not the BASELINE workload)."""
     V = geo["lm"]["vocab"]
     rng = np.random.default_rng(seed)
-    n_ids = 129
+    n_ids = 129 if text_lens is None else text_lens[1]
     ids = rng.integers(3, V, size=(b, n_ids), dtype=np.int64)
     labels = ids.copy()
     labels[:, :64] = -100
     ids[:, 35] = -200
     labels[:, 35] = -100
     mask = np.ones_like(ids, dtype=bool)
+    if text_lens is not None:
+        for i, n in enumerate(rng.integers(text_lens[0], text_lens[1] + 1, size=b)):
+            mask[i, n:] = False
+            ids[i, n:] = 0
+            labels[i, n:] = -100
     g = torch.Generator().manual_seed(seed)
     img = geo["vision"]["image"]
     images = [torch.randn(3, img, img, generator=g).to(torch.bfloat16) for _ in range(b)]
@@ -176,6 +183,8 @@ def main():
                     help="cxr = BASELINE configs 2/3 (headline); anyres = config 4 (S=3056); lora = config 5 (r=64 adapters); "
                          "radvlm = SURVEY 8f.1 (Qwen2-7B + SigLIP, anyres_max_9, all parts tunable; use --geometry llava_ov_qwen2_7b --batch 2)")
     ap.add_argument("--lr", type=float, default=2e-5)
+    ap.add_argument("--text-lens", default=None, help="lo,hi: variable per-sample text lengths (cxr workload only; not the BASELINE workload)")
+    ap.add_argument("--packed", default="auto", choices=["auto", "0", "1"], help="packed (varlen) decoder batches")
     args = ap.parse_args()
 
     from radvlm_amd import lib, ops
@@ -211,10 +220,14 @@ def main():
     if args.workload == "radvlm":
         kw = dict(merge_type="spatial_unpad", image_aspect_ratio="anyres_max_9", image_grid_pinpoints="(1x1),...,(6x6)",
                   train_vision_tower=True)
+    kw["packed"] = {"auto": "auto", "0": False, "1": True}[args.packed]
     eng = LlavaEngine(geo, device=f"cuda:{local}", init="fast", seed=0, process_group=pg, **kw)
     eng.init_optimizer()
     make = {"anyres": synthetic_batch_anyres, "radvlm": synthetic_batch_radvlm}.get(args.workload, synthetic_batch)
-    batch = make(geo, args.batch, seed=1234 + rank)
+    if args.text_lens and args.workload == "cxr":
+        batch = synthetic_batch(geo, args.batch, seed=1234 + rank, text_lens=tuple(int(x) for x in args.text_lens.split(",")))
+    else:
+        batch = make(geo, args.batch, seed=1234 + rank)
 
     def step():
         loss = eng.forward(*batch)
@@ -280,7 +293,8 @@ def main():
                                    f"{ {'anyres': 'anyres 5 tiles, S=3056', 'radvlm': 'anyres_max_9 10 tiles, S=7499'}.get(args.workload, 'S=704')}, "
                                    f"{args.batch} pairs/GPU/step", "global_batch": args.batch * world,
                        "seq_len": {"anyres": 3056, "radvlm": 7499}.get(args.workload, 704),
-                       "parallelism": f"dp{world}", "final_loss": final_loss},
+                       "parallelism": f"dp{world}", "final_loss": final_loss,
+                       **({"text_lens": args.text_lens, "packed": args.packed} if args.text_lens else {})},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -124,17 +124,29 @@ int rv_attn_bwd(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const 
 /* Grouped-query form (Qwen2: language_model/llava_qwen.py:46-58 -> HF Qwen2Attention with num_key_value_heads < heads;
  * repeat_kv modeling_llama.py:201-210): k / v / kT / vT / dk / dv hold H_kv heads, query head h uses key/value head
  * h / (H / H_kv); the dK/dV pass sums the group's query heads in registers (no expanded copies).  H % H_kv == 0.
+ * Packed (variable-length) batches -- SURVEY 8f.2, no padding rows: cu_rows (int32 [B+1], device; may be NULL) gives the
+ * first token row of every sample in q/k/v/out/dq/dk/dv (total_rows = cu_rows[B], host copy); S is then the LONGEST sample (grid extent, S_pad >= S), `lens` is
+ * ignored, and the [b,h,hd,S_pad] transposed operands and lse/delta stay per-sample padded (rv_transpose_bf16_varlen).
  * Optional `workspace` (>= 2*B*S*H*hd*2 bytes, 16-byte aligned; may be NULL): when the dK/dV grid (key blocks x H_kv x B)
  * is too small to balance a long causal sequence over the chip, the pass runs one block per QUERY head into the
  * workspace and a deterministic group sum folds the partials. */
 int rv_attn_fwd_gqa(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* vT, void* out, int64_t ld_o,
-                    float* lse, const int32_t* lens, int B, int H, int H_kv, int S, int S_pad, int hd, int causal,
-                    float scale, const void* zeros16, void* stream);
+                    float* lse, const int32_t* lens, const int32_t* cu_rows, int B, int H, int H_kv, int S, int S_pad, int hd,
+                    int causal, float scale, const void* zeros16, void* stream);
 int rv_attn_bwd_gqa(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v, const void* o,
                     int64_t ld_o, const void* dout, int64_t ld_do, const void* qT, const void* kT, const void* doT,
                     const float* lse, float* delta, void* dq, int64_t ld_dq, void* dk, int64_t ld_dk, void* dv,
-                    int64_t ld_dv, const int32_t* lens, int B, int H, int H_kv, int S, int S_pad, int hd, int causal,
-                    float scale, void* workspace, int64_t workspace_bytes, const void* zeros16, void* stream);
+                    int64_t ld_dv, const int32_t* lens, const int32_t* cu_rows, int total_rows, int B, int H, int H_kv, int S,
+                    int S_pad, int hd, int causal, float scale, void* workspace, int64_t workspace_bytes, const void* zeros16,
+                    void* stream);
+
+/* rv_transpose_bf16 for packed batches: batch b0 reads rows [cu_rows[b0], cu_rows[b0+1]) of `in` (R_max = longest). */
+int rv_transpose_bf16_varlen(const void* in, int64_t in_ld, const int32_t* cu_rows, int64_t in_bs1, void* out, int64_t out_ld,
+                             int64_t out_bs0, int64_t out_bs1, int R_max, int C, int R_pad, int nb0, int nb1, int perm32,
+                             void* stream);
+/* rv_rope_inplace with an explicit position per token row (packed batches: position = row - first row of its sample). */
+int rv_rope_inplace_pos(void* x, int64_t ld, const float* cos_sin, const int32_t* positions, int rows, int heads, int hd,
+                        int nsec, int dir, void* stream);
 
 /* ---- MLP activations ------------------------------------------------------------------------------------------------
  * LlamaMLP (modeling_llama.py:226): act[r, f] = silu(gu[r, f]) * gu[r, F + f]   (gu = fused gate|up output). */

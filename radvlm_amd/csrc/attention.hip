@@ -23,6 +23,7 @@ struct AttnParams {
     bf16 *out, *dq, *dk, *dv;
     float *lse, *delta;
     const int* lens;
+    const int* cu;      // packed (varlen) batches: sample b owns token rows [cu[b], cu[b+1]) of q/k/v/out; NULL = b*S padded layout
     const bf16* zeros;
     long ld_q, ld_k, ld_v, ld_o, ld_do, ld_dq, ld_dk, ld_dv;
     int B, H, S, S_pad;
@@ -73,22 +74,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wid = wave_id(), lane = lane_id(), g = lane >> 4, c = lane & 15;
     const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int S = P.S, q0 = qblk * 128 + wid * 32;
-    const int len = P.lens ? P.lens[b] : S;
+    const long rb = P.cu ? (long)P.cu[b] : (long)b * P.S;              // first token row of this sample
+    const int S = P.cu ? P.cu[b + 1] - P.cu[b] : P.S, q0 = qblk * 128 + wid * 32;
+    if (qblk * 128 >= S) return;                                        // packed batches: shorter samples need fewer blocks
+    const int len = (P.lens && !P.cu) ? P.lens[b] : S;
     const float sl2 = P.scale * LOG2E;
 
     bf16x8 qf[2][KS];
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs) {
         const int row = min(q0 + qs * 16 + c, S - 1);
-        const bf16* p = P.q + (long)(b * S + row) * P.ld_q + h * HD + g * 8;
+        const bf16* p = P.q + (rb + row) * P.ld_q + h * HD + g * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[qs][ks] = *(const bf16x8*)(p + ks * 32);
     }
     const int kv_end = CAUSAL ? min(len, qblk * 128 + 128) : len;
     const int ntiles = (kv_end + 63) >> 6;
     const int hk = h / P.nrep;
-    const bf16* kbase = P.k + (long)b * S * P.ld_k + hk * HD;
+    const bf16* kbase = P.k + rb * P.ld_k + hk * HD;
     const bf16* vtbase = P.vT + (long)(b * P.Hkv + hk) * HD * P.S_pad;
 
     float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
         const int qidx = q0 + qs * 16 + c;
         if (qidx >= S) continue;
         const float inv = 1.f / lt;
-        bf16* op = P.out + (long)(b * S + qidx) * P.ld_o + h * HD + 4 * g;
+        bf16* op = P.out + (rb + qidx) * P.ld_o + h * HD + 4 * g;
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
             const f32x4 v = o[qs][db] * inv;
@@ -201,8 +204,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dq_kernel(AttnParams
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wid = wave_id(), lane = lane_id(), g = lane >> 4, c = lane & 15;
     const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int S = P.S, q0 = qblk * (32 * NW) + wid * 32;
-    const int len = P.lens ? P.lens[b] : S;
+    const long rb = P.cu ? (long)P.cu[b] : (long)b * P.S;
+    const int S = P.cu ? P.cu[b + 1] - P.cu[b] : P.S, q0 = qblk * (32 * NW) + wid * 32;
+    if (qblk * (32 * NW) >= S) return;
+    const int len = (P.lens && !P.cu) ? P.lens[b] : S;
     const float sl2 = P.scale * LOG2E;
 
     bf16x8 qf[2][KS], dof[2][KS];
@@ -210,9 +215,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dq_kernel(AttnParams
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs) {
         const int row = min(q0 + qs * 16 + c, S - 1);
-        const bf16* p = P.q + (long)(b * S + row) * P.ld_q + h * HD + g * 8;
-        const bf16* d = P.dout + (long)(b * S + row) * P.ld_do + h * HD + g * 8;
-        const bf16* op = P.o + (long)(b * S + row) * P.ld_o + h * HD + g * 8;
+        const bf16* p = P.q + (rb + row) * P.ld_q + h * HD + g * 8;
+        const bf16* d = P.dout + (rb + row) * P.ld_do + h * HD + g * 8;
+        const bf16* op = P.o + (rb + row) * P.ld_o + h * HD + g * 8;
         float dsum = 0.f;   // delta = rowsum(dO * O), fused here (this lane owns 8 * KS of the row's HD products)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -231,8 +236,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dq_kernel(AttnParams
     const int kv_end = CAUSAL ? min(len, (qblk + 1) * (32 * NW)) : len;
     const int ntiles = (kv_end + 63) >> 6;
     const int hk = h / P.nrep;
-    const bf16* kbase = P.k + (long)b * S * P.ld_k + hk * HD;
-    const bf16* vbase = P.v + (long)b * S * P.ld_v + hk * HD;
+    const bf16* kbase = P.k + rb * P.ld_k + hk * HD;
+    const bf16* vbase = P.v + rb * P.ld_v + hk * HD;
     const bf16* ktbase = P.kT + (long)(b * P.Hkv + hk) * HD * P.S_pad;
 
     f32x4 dq[2][DB];
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dq_kernel(AttnParams
     for (int qs = 0; qs < 2; ++qs) {
         const int qidx = q0 + qs * 16 + c;
         if (qidx >= S) continue;
-        bf16* op = P.dq + (long)(b * S + qidx) * P.ld_dq + h * HD + 4 * g;
+        bf16* op = P.dq + (rb + qidx) * P.ld_dq + h * HD + 4 * g;
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
             const f32x4 v = dq[qs][db] * P.scale;
@@ -326,16 +331,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dkv_kernel(AttnParam
     const int wid = wave_id(), lane = lane_id(), g = lane >> 4, c = lane & 15;
     const int kblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     constexpr int KPB = NW * NKB * 16;   // keys per block
-    const int S = P.S, k0 = kblk * KPB + wid * (16 * NKB);
-    const int len = P.lens ? P.lens[b] : S;
+    const long rb = P.cu ? (long)P.cu[b] : (long)b * P.S;
+    const int S = P.cu ? P.cu[b + 1] - P.cu[b] : P.S, k0 = kblk * KPB + wid * (16 * NKB);
+    if (kblk * KPB >= S) return;
+    const int len = (P.lens && !P.cu) ? P.lens[b] : S;
     const float sl2 = P.scale * LOG2E;
 
     bf16x8 kf[NKB][KS], vf[NKB][KS];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
         const int row = min(k0 + kb * 16 + c, S - 1);
-        const bf16* kp = P.k + (long)(b * S + row) * P.ld_k + (h / P.kdiv) * HD + g * 8;
-        const bf16* vp = P.v + (long)(b * S + row) * P.ld_v + (h / P.kdiv) * HD + g * 8;
+        const bf16* kp = P.k + (rb + row) * P.ld_k + (h / P.kdiv) * HD + g * 8;
+        const bf16* vp = P.v + (rb + row) * P.ld_v + (h / P.kdiv) * HD + g * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) { kf[kb][ks] = *(const bf16x8*)(kp + ks * 32); vf[kb][ks] = *(const bf16x8*)(vp + ks * 32); }
     }
@@ -359,8 +366,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dkv_kernel(AttnParam
     auto stage = [&](int it, char* dst) {
         const int hq = h * P.qrep + it / nt;
         const int qt0 = (t0 + it % nt) * 64;
-        const bf16* qbase = P.q + (long)b * S * P.ld_q + hq * HD;
-        const bf16* dobase = P.dout + (long)b * S * P.ld_do + hq * HD;
+        const bf16* qbase = P.q + rb * P.ld_q + hq * HD;
+        const bf16* dobase = P.dout + rb * P.ld_do + hq * HD;
         const bf16* qtbase = P.qT + (long)(b * P.H + hq) * HD * P.S_pad;
         const bf16* dotbase = P.doT + (long)(b * P.H + hq) * HD * P.S_pad;
         const float* lsebase = P.lse + (long)(b * P.H + hq) * P.S_pad;
@@ -451,8 +458,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dkv_kernel(AttnParam
     for (int kb = 0; kb < NKB; ++kb) {
         const int kidx = k0 + kb * 16 + c;
         if (kidx >= S) continue;
-        bf16* vp = P.dv + (long)(b * S + kidx) * P.ld_dv + h * HD + 4 * g;
-        bf16* kp = P.dk + (long)(b * S + kidx) * P.ld_dk + h * HD + 4 * g;
+        bf16* vp = P.dv + (rb + kidx) * P.ld_dv + h * HD + 4 * g;
+        bf16* kp = P.dk + (rb + kidx) * P.ld_dk + h * HD + 4 * g;
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
             const f32x4 a = dv[db][kb], bb = dk[db][kb] * P.scale;
@@ -491,13 +498,13 @@ bool aligned_ok(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 }  // namespace
 
 extern "C" int rv_attn_fwd_gqa(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* vT, void* out,
-                               int64_t ld_o, float* lse, const int32_t* lens, int B, int H, int H_kv, int S, int S_pad, int HD,
-                               int causal, float scale, const void* zeros16, void* stream) {
+                               int64_t ld_o, float* lse, const int32_t* lens, const int32_t* cu_rows, int B, int H, int H_kv,
+                               int S, int S_pad, int HD, int causal, float scale, const void* zeros16, void* stream) {
     if (!q || !k || !vT || !out || !zeros16 || B <= 0 || H <= 0 || S <= 0 || H_kv <= 0 || H % H_kv) return RV_ERR_ARG;
     if ((HD != 64 && HD != 128) || (S_pad & 63) || S_pad < S) return RV_ERR_ARG;
     if ((ld_q & 7) || (ld_k & 7) || (ld_o & 3) || !aligned_ok(q) || !aligned_ok(k) || !aligned_ok(vT)) return RV_ERR_ARG;
     AttnParams P = {};
-    P.q = (const bf16*)q; P.k = (const bf16*)k; P.vT = (const bf16*)vT; P.out = (bf16*)out; P.lse = lse; P.lens = lens;
+    P.q = (const bf16*)q; P.k = (const bf16*)k; P.vT = (const bf16*)vT; P.out = (bf16*)out; P.lse = lse; P.lens = lens; P.cu = cu_rows;
     P.zeros = (const bf16*)zeros16; P.ld_q = ld_q; P.ld_k = ld_k; P.ld_o = ld_o;
     P.B = B; P.H = H; P.S = S; P.S_pad = S_pad; P.scale = scale; P.Hkv = H_kv; P.nrep = H / H_kv;
     dim3 grid((S + 127) / 128, H, B);
@@ -516,14 +523,14 @@ extern "C" int rv_attn_fwd_gqa(const void* q, int64_t ld_q, const void* k, int64
 extern "C" int rv_attn_fwd(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* vT, void* out,
                            int64_t ld_o, float* lse, const int32_t* lens, int B, int H, int S, int S_pad, int HD,
                            int causal, float scale, const void* zeros16, void* stream) {
-    return rv_attn_fwd_gqa(q, ld_q, k, ld_k, vT, out, ld_o, lse, lens, B, H, H, S, S_pad, HD, causal, scale, zeros16, stream);
+    return rv_attn_fwd_gqa(q, ld_q, k, ld_k, vT, out, ld_o, lse, lens, nullptr, B, H, H, S, S_pad, HD, causal, scale, zeros16, stream);
 }
 
 extern "C" int rv_attn_bwd_gqa(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v,
                                const void* o, int64_t ld_o, const void* dout, int64_t ld_do, const void* qT, const void* kT,
                                const void* doT, const float* lse, float* delta, void* dq, int64_t ld_dq, void* dk,
-                               int64_t ld_dk, void* dv, int64_t ld_dv, const int32_t* lens, int B, int H, int H_kv, int S,
-                               int S_pad, int HD, int causal, float scale, void* workspace, int64_t workspace_bytes,
+                               int64_t ld_dk, void* dv, int64_t ld_dv, const int32_t* lens, const int32_t* cu_rows, int total_rows,
+                               int B, int H, int H_kv, int S, int S_pad, int HD, int causal, float scale, void* workspace, int64_t workspace_bytes,
                                const void* zeros16, void* stream) {
     if (!q || !k || !v || !o || !dout || !qT || !kT || !doT || !lse || !delta || !dq || !dk || !dv || !zeros16) return RV_ERR_ARG;
     if (H_kv <= 0 || H <= 0 || H % H_kv) return RV_ERR_ARG;
@@ -533,7 +540,7 @@ extern "C" int rv_attn_bwd_gqa(const void* q, int64_t ld_q, const void* k, int64
     AttnParams P = {};
     P.q = (const bf16*)q; P.k = (const bf16*)k; P.v = (const bf16*)v; P.o = (const bf16*)o; P.dout = (const bf16*)dout;
     P.qT = (const bf16*)qT; P.kT = (const bf16*)kT; P.doT = (const bf16*)doT;
-    P.dq = (bf16*)dq; P.dk = (bf16*)dk; P.dv = (bf16*)dv; P.lse = (float*)lse; P.delta = delta; P.lens = lens;
+    P.dq = (bf16*)dq; P.dk = (bf16*)dk; P.dv = (bf16*)dv; P.lse = (float*)lse; P.delta = delta; P.lens = lens; P.cu = cu_rows;
     P.zeros = (const bf16*)zeros16;
     P.ld_q = ld_q; P.ld_k = ld_k; P.ld_v = ld_v; P.ld_o = ld_o; P.ld_do = ld_do; P.ld_dq = ld_dq; P.ld_dk = ld_dk; P.ld_dv = ld_dv;
     P.B = B; P.H = H; P.S = S; P.S_pad = S_pad; P.scale = scale; P.Hkv = H_kv; P.nrep = H / H_kv;
@@ -544,12 +551,14 @@ extern "C" int rv_attn_bwd_gqa(const void* q, int64_t ld_q, const void* k, int64
     AttnParams PK = P;        // parameters of the dK/dV pass
     PK.kdiv = 1; PK.qrep = P.nrep;
     // few key/value heads and a long causal sequence: per-query-head blocks + a group sum balance better than per-group blocks
-    const int64_t need = 2 * (int64_t)B * S * H * HD * 2;
+    const long rows_all = cu_rows ? (long)total_rows : (long)B * S;      // token rows of q/k/v (packed: cu_rows[B])
+    if (cu_rows && total_rows <= 0) return RV_ERR_ARG;
+    const int64_t need = 2 * (int64_t)rows_all * H * HD * 2;
     const bool expand = P.nrep > 1 && workspace && workspace_bytes >= need && (((uintptr_t)workspace) & 15) == 0 &&
                         (long)grid_dkv.x * H_kv * B < 2048;
     if (expand) {
         PK.kdiv = P.nrep; PK.qrep = 1;
-        PK.dk = (bf16*)workspace; PK.dv = (bf16*)workspace + (int64_t)B * S * H * HD;
+        PK.dk = (bf16*)workspace; PK.dv = (bf16*)workspace + (int64_t)rows_all * H * HD;
         PK.ld_dk = PK.ld_dv = (long)H * HD;
         grid_dkv.y = H;
     }
@@ -566,7 +575,7 @@ extern "C" int rv_attn_bwd_gqa(const void* q, int64_t ld_q, const void* k, int64
     else { if (causal) LAUNCH_BWD(64, true); else LAUNCH_BWD(64, false); }
 #undef LAUNCH_BWD
     if (expand) {
-        const long rows = (long)B * S, total = rows * (H_kv * HD / 8);
+        const long rows = rows_all, total = rows * (H_kv * HD / 8);
         hipLaunchKernelGGL(group_sum_heads_kernel, dim3((total + 255) / 256), dim3(256), 0, st, PK.dk, PK.ld_dk, P.dk, P.ld_dk, rows, H_kv, P.nrep, HD);
         hipLaunchKernelGGL(group_sum_heads_kernel, dim3((total + 255) / 256), dim3(256), 0, st, PK.dv, PK.ld_dv, P.dv, P.ld_dv, rows, H_kv, P.nrep, HD);
     }
@@ -579,5 +588,5 @@ extern "C" int rv_attn_bwd(const void* q, int64_t ld_q, const void* k, int64_t l
                            int64_t ld_dk, void* dv, int64_t ld_dv, const int32_t* lens, int B, int H, int S, int S_pad,
                            int HD, int causal, float scale, const void* zeros16, void* stream) {
     return rv_attn_bwd_gqa(q, ld_q, k, ld_k, v, ld_v, o, ld_o, dout, ld_do, qT, kT, doT, lse, delta, dq, ld_dq, dk, ld_dk, dv, ld_dv,
-                           lens, B, H, H, S, S_pad, HD, causal, scale, nullptr, 0, zeros16, stream);
+                           lens, nullptr, 0, B, H, H, S, S_pad, HD, causal, scale, nullptr, 0, zeros16, stream);
 }

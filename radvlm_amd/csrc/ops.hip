@@ -275,7 +275,7 @@ __global__ __launch_bounds__(TPB) void colsum_partial_kernel(const bf16* x, long
 }
 
 // ------------------------------------------------------------------------------------------------ RoPE
-__global__ void rope_kernel(bf16* x, long ld, const float* cs, int rows, int S, int heads, int hd, int nsec, int dir) {
+__global__ void rope_kernel(bf16* x, long ld, const float* cs, const int* positions, int rows, int S, int heads, int hd, int nsec, int dir) {
     const int per_head = hd / 16;  // threads per head (8 pairs each)
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)rows * nsec * heads * per_head;
@@ -284,7 +284,7 @@ __global__ void rope_kernel(bf16* x, long ld, const float* cs, int rows, int S, 
     const int h = (tid / per_head) % heads;
     const int sec = (tid / ((long)per_head * heads)) % nsec;
     const long row = tid / ((long)per_head * heads * nsec);
-    const int pos = row % S;
+    const int pos = positions ? positions[row] : (int)(row % S);
     bf16* p = x + row * ld + (long)sec * heads * hd + h * hd + t * 8;
     float a[8], b[8];
     ld8(p, a);
@@ -565,10 +565,12 @@ __global__ void clip_embed_kernel(const bf16* patch_out, const bf16* cls, const 
 // ------------------------------------------------------------------------------------------------ transpose
 // 64x64 tiles through LDS; out row c holds in[.., c] for r in [0, R_pad) (zeros beyond R).
 __global__ __launch_bounds__(TPB) void transpose_kernel(const bf16* in, long in_ld, long in_bs0, long in_bs1, bf16* out, long out_ld,
-                                                        long out_bs0, long out_bs1, int R, int C, int R_pad, int nb1, int perm32) {
+                                                        long out_bs0, long out_bs1, int R, int C, int R_pad, int nb1, int perm32,
+                                                        const int* cu) {
     __shared__ bf16 tile[64][72];
     const int bz = blockIdx.z, b0 = bz / nb1, b1 = bz % nb1;
-    const bf16* src = in + b0 * in_bs0 + b1 * in_bs1;
+    const bf16* src = in + (cu ? (long)cu[b0] * in_ld : b0 * in_bs0) + b1 * in_bs1;
+    if (cu) R = cu[b0 + 1] - cu[b0];       // packed batches: this sample's own row count (zero padded up to R_pad)
     bf16* dst = out + b0 * out_bs0 + b1 * out_bs1;
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
 #pragma unroll
@@ -745,7 +747,13 @@ extern "C" int rv_colsum_partial_bf16(const void* x, int64_t ld, int rows, int c
 extern "C" int rv_rope_inplace(void* x, int64_t ld, const float* cos_sin, int rows, int S, int heads, int hd, int nsec, int dir, void* stream) {
     if (!x || !cos_sin || rows <= 0 || S <= 0 || (hd & 15) || (ld & 7)) return RV_ERR_ARG;
     const long total = (long)rows * nsec * heads * (hd / 16);
-    hipLaunchKernelGGL(rope_kernel, dim3(nblocks(total, 256)), dim3(256), 0, ST, (bf16*)x, (long)ld, cos_sin, rows, S, heads, hd, nsec, dir);
+    hipLaunchKernelGGL(rope_kernel, dim3(nblocks(total, 256)), dim3(256), 0, ST, (bf16*)x, (long)ld, cos_sin, (const int*)nullptr, rows, S, heads, hd, nsec, dir);
+    return rv_check_launch();
+}
+extern "C" int rv_rope_inplace_pos(void* x, int64_t ld, const float* cos_sin, const int32_t* positions, int rows, int heads, int hd, int nsec, int dir, void* stream) {
+    if (!x || !cos_sin || !positions || rows <= 0 || (hd & 15) || (ld & 7)) return RV_ERR_ARG;
+    const long total = (long)rows * nsec * heads * (hd / 16);
+    hipLaunchKernelGGL(rope_kernel, dim3(nblocks(total, 256)), dim3(256), 0, ST, (bf16*)x, (long)ld, cos_sin, positions, rows, 1, heads, hd, nsec, dir);
     return rv_check_launch();
 }
 extern "C" int rv_swiglu_fwd(const void* gu, int64_t ld_gu, void* act, int64_t ld_act, int rows, int F, void* stream) {
@@ -842,7 +850,19 @@ extern "C" int rv_transpose_bf16(const void* in, int64_t in_ld, int64_t in_bs0, 
     if (perm32 && (R_pad & 63)) return RV_ERR_ARG;
     dim3 grid((R_pad + 63) / 64, (C + 63) / 64, nb0 * nb1);
     hipLaunchKernelGGL(transpose_kernel, grid, dim3(TPB), 0, ST, (const bf16*)in, (long)in_ld, (long)in_bs0, (long)in_bs1, (bf16*)out,
-                       (long)out_ld, (long)out_bs0, (long)out_bs1, R, C, R_pad, nb1, perm32);
+                       (long)out_ld, (long)out_bs0, (long)out_bs1, R, C, R_pad, nb1, perm32, (const int*)nullptr);
+    return rv_check_launch();
+}
+extern "C" int rv_transpose_bf16_varlen(const void* in, int64_t in_ld, const int32_t* cu_rows, int64_t in_bs1, void* out, int64_t out_ld,
+                                        int64_t out_bs0, int64_t out_bs1, int R_max, int C, int R_pad, int nb0, int nb1, int perm32,
+                                        void* stream) {
+    if (!in || !out || !cu_rows || R_max <= 0 || C <= 0 || R_pad < R_max || (R_pad & 7) || nb0 <= 0 || nb1 <= 0) return RV_ERR_ARG;
+    if ((in_ld & 7) || (out_ld & 7) || (in_bs1 & 7) || (out_bs0 & 7) || (out_bs1 & 7)) return RV_ERR_ARG;
+    if ((((uintptr_t)in) | ((uintptr_t)out)) & 15) return RV_ERR_ARG;
+    if (perm32 && (R_pad & 63)) return RV_ERR_ARG;
+    dim3 grid((R_pad + 63) / 64, (C + 63) / 64, nb0 * nb1);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(TPB), 0, ST, (const bf16*)in, (long)in_ld, 0L, (long)in_bs1, (bf16*)out,
+                       (long)out_ld, (long)out_bs0, (long)out_bs1, R_max, C, R_pad, nb1, perm32, cu_rows);
     return rv_check_launch();
 }
 extern "C" int rv_adamw(void* p, float* master, const void* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,

@@ -33,8 +33,11 @@ def _ru(x, m):
 class LlavaEngine:
     def __init__(self, geo, device="cuda", merge_type="flat", image_aspect_ratio="square", image_grid_pinpoints=None,
                  max_len=None, init="portable", seed=0, rms_eps=1e-5, rope_theta=10000.0, process_group=None,
-                 bucket_layers=1, train_vision_tower=False, lora=None):
+                 bucket_layers=1, train_vision_tower=False, lora=None, packed="auto"):
         self.geo = geo
+        # packed (varlen) decoder batches: True / False / "auto" (pack when the samples of a batch differ in length): the decoder
+        # then runs on sum(len_b) token rows instead of B * max(len_b) -- no padding rows through GEMMs, norms, CE
+        self.packed = packed
         self.v, self.l = geo["vision"], geo["lm"]
         self.device = torch.device(device)
         self.merge_type = merge_type
@@ -404,10 +407,26 @@ class LlavaEngine:
         table = self.encode_images(pix.contiguous(), save=ctx, plan=plan)
         B = len(images)
         S = plan["S"]
-        M = B * S
         s_pad = _ru(S, 64)
+        lens_np = plan["lens"]
+        packed = bool(self.packed) if self.packed != "auto" else bool((lens_np != S).any())
+        cu = pos = valid_idx = None
+        if packed:
+            valid = plan["attention_mask"].reshape(-1)
+            p2k = np.cumsum(valid) - 1                                        # padded flat row -> packed row
+            remap = lambda a: np.where(a >= 0, p2k[np.maximum(a, 0)], -1).astype(np.int32)
+            plan = dict(plan, idx=plan["idx"][valid], feat_pos=remap(plan["feat_pos"]), newline_pos=remap(plan["newline_pos"]),
+                        tok_pos=remap(plan["tok_pos"]))
+            ctx["plan"] = plan
+            M = int(valid.sum())
+            cu = torch.from_numpy(np.concatenate([[0], np.cumsum(lens_np)]).astype(np.int32)).to(dev, non_blocking=True)
+            pos = torch.from_numpy((np.arange(B * S, dtype=np.int32) % S)[valid]).to(dev, non_blocking=True)
+            valid_idx = np.nonzero(valid)[0]
+            lens = None
+        else:
+            M = B * S
+            lens = torch.from_numpy(lens_np).to(dev, non_blocking=True)
         idx = torch.from_numpy(plan["idx"]).to(dev, non_blocking=True)
-        lens = torch.from_numpy(plan["lens"]).to(dev, non_blocking=True)
         x = ops.gather_rows(idx, d, self.W("model.embed_tokens.weight"), table)
         cs = self.rope_table(S)
         layers = []
@@ -419,9 +438,9 @@ class LlavaEngine:
                 qkv = self._lora_linear(h1, lv["qkv"], i, self._MODS_QKV(d), sv)
             else:
                 qkv = ops.gemm_nt(h1, lv["qkv"], bias=lv.get("bqkv"))
-            ops.rope_inplace(qkv, cs, S, H + Hkv, hd, 1, 1)          # q heads then k heads: one run of H + Hkv heads
-            vT = ops.transpose_heads(qkv[:, d + kvd:], B, S, Hkv, hd, s_pad)
-            attn, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d:d + kvd], vT, B, S, H, hd, s_pad, causal=True, lens=lens, kv_heads=Hkv)
+            ops.rope_inplace(qkv, cs, S, H + Hkv, hd, 1, 1, positions=pos)   # q heads then k heads: one run of H + Hkv heads
+            vT = ops.transpose_heads(qkv[:, d + kvd:], B, S, Hkv, hd, s_pad, cu=cu)
+            attn, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d:d + kvd], vT, B, S, H, hd, s_pad, causal=True, lens=lens, kv_heads=Hkv, cu=cu)
             if self.lora:
                 x_mid = self._lora_linear(attn, lv["o"], i, (("self_attn.o_proj", 0, d),), sv, residual=x)
             else:
@@ -444,12 +463,21 @@ class LlavaEngine:
         tgt = shifted_labels(plan["labels"])
         count = int((tgt != -100).sum())
         inv = (1.0 / count) if count > 0 else float("nan")
-        tgt_t = torch.from_numpy(tgt.reshape(-1)).to(dev, non_blocking=True)
-        logits_out = ops.to_f32(logits).view(B, S, V) if want_logits else None
+        tgt = tgt.reshape(-1)
+        if packed:
+            tgt = tgt[valid_idx]
+        tgt_t = torch.from_numpy(tgt).to(dev, non_blocking=True)
+        logits_out = None
+        if want_logits and packed:      # callers see the reference's padded [B, S, V] shape (padding rows zero)
+            logits_out = torch.zeros(B * S, V, dtype=torch.float32, device=dev)
+            logits_out[torch.from_numpy(valid_idx).to(dev)] = ops.to_f32(logits)
+            logits_out = logits_out.view(B, S, V)
+        elif want_logits:
+            logits_out = ops.to_f32(logits).view(B, S, V)
         # CE writes dlogits (scaled by loss_scale/count/world) over the logits buffer
         gscale = loss_scale / self.world
         loss, _ = self._cross_entropy(logits, tgt_t, V, inv, gscale)
-        ctx.update(B=B, S=S, M=M, s_pad=s_pad, lens=lens, layers=layers, x_last=x, rstdN=rstdN, hN=hN, dlogits=logits,
+        ctx.update(B=B, S=S, M=M, s_pad=s_pad, lens=lens, cu=cu, pos=pos, layers=layers, x_last=x, rstdN=rstdN, hN=hN, dlogits=logits,
                    table_rows=table.shape[0], count=count)
         self.ctx = ctx
         self.last_logits = logits_out
@@ -543,7 +571,7 @@ class LlavaEngine:
         l = self.l
         d, F, H, V, L = l["d"], l["ffn"], l["heads"], l["vocab"], l["layers"]
         hd, Hkv, kvd = self.hd, self.Hkv, self.kvd
-        B, S, M, s_pad, lens = c["B"], c["S"], c["M"], c["s_pad"], c["lens"]
+        B, S, M, s_pad, lens, cu, pos = c["B"], c["S"], c["M"], c["s_pad"], c["lens"], c["cu"], c["pos"]
         acc = self.grad_accum_started
         cs = self.rope_table(S)
         # head
@@ -566,8 +594,8 @@ class LlavaEngine:
             qkv = a["qkv"]
             dqkv = torch.empty_like(qkv)
             ops.attn_bwd(qkv[:, :d], qkv[:, d:d + kvd], qkv[:, d + kvd:], a["attn"], dattn, a["lse"], B, S, H, hd, s_pad, True,
-                         lens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:d + kvd], dv=dqkv[:, d + kvd:], kv_heads=Hkv)
-            ops.rope_inplace(dqkv, cs, S, H + Hkv, hd, 1, -1)
+                         lens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:d + kvd], dv=dqkv[:, d + kvd:], kv_heads=Hkv, cu=cu)
+            ops.rope_inplace(dqkv, cs, S, H + Hkv, hd, 1, -1, positions=pos)
             if "bqkv" in gv:
                 ops.bias_grad(dqkv, out=gv["bqkv"], accumulate=acc)
             dh1 = self._lm_linear_bwd(dqkv, a["h1"], lv["qkv"], gv.get("qkv"), i, self._MODS_QKV(d), sv)

@@ -42,11 +42,14 @@ _SIGS = {
     "rv_attn_bwd": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p,
                     _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i32, _i32,
                     _i32, _i32, _i32, _i32, _f32, _c_void_p, _c_void_p],
-    "rv_attn_fwd_gqa": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32,
-                        _i32, _i32, _i32, _f32, _c_void_p, _c_void_p],
+    "rv_attn_fwd_gqa": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i32,
+                        _i32, _i32, _i32, _i32, _f32, _c_void_p, _c_void_p],
     "rv_attn_bwd_gqa": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p,
-                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i32, _i32,
-                        _i32, _i32, _i32, _i32, _i32, _f32, _c_void_p, _i64, _c_void_p, _c_void_p],
+                        _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i32,
+                        _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _c_void_p, _i64, _c_void_p, _c_void_p],
+    "rv_transpose_bf16_varlen": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32,
+                                 _c_void_p],
+    "rv_rope_inplace_pos": [_c_void_p, _i64, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i32, _c_void_p],
     "rv_gelu_tanh_fwd": [_c_void_p, _c_void_p, _i64, _c_void_p],
     "rv_gelu_tanh_bwd": [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p],
     "rv_weighted_segment_sum_rows": [_c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i32, _c_void_p, _i64, _i32,

@@ -106,15 +106,19 @@ def transpose(x, r_pad=None, out=None):
     return out
 
 
-def transpose_heads(x, B, S, H, hd, s_pad, out=None, perm32=True):
+def transpose_heads(x, B, S, H, hd, s_pad, out=None, perm32=True, cu=None):
     """x: token-major view [(b*S+s), H*hd] (row stride ld) -> [B,H,hd,s_pad] (zero padded along s).
-    perm32 (what the attention kernels expect): the sequence axis is stored in MFMA contraction order per group of 32."""
+    perm32 (what the attention kernels expect): the sequence axis is stored in MFMA contraction order per group of 32.
+    cu (int32 [B+1], packed batches): sample b owns rows [cu[b], cu[b+1]) of x; S = the longest sample."""
     _chk(x)
-    assert x.shape == (B * S, H * hd) and x.stride(1) == 1
+    assert x.shape[1] == H * hd and x.stride(1) == 1 and (cu is not None or x.shape[0] == B * S)
     if out is None:
         out = torch.empty(B, H, hd, s_pad, dtype=BF16, device=x.device)
     ld = x.stride(0)
-    lib.call("rv_transpose_bf16", x, ld, S * ld, hd, out, s_pad, H * hd * s_pad, hd * s_pad, S, hd, s_pad, B, H, int(perm32))
+    if cu is not None:
+        lib.call("rv_transpose_bf16_varlen", x, ld, cu, hd, out, s_pad, H * hd * s_pad, hd * s_pad, S, hd, s_pad, B, H, int(perm32))
+    else:
+        lib.call("rv_transpose_bf16", x, ld, S * ld, hd, out, s_pad, H * hd * s_pad, hd * s_pad, S, hd, s_pad, B, H, int(perm32))
     return out
 
 
@@ -226,42 +230,48 @@ def rope_table(S, hd, theta=10000.0, device="cuda", round_bf16=True):
     return cs.contiguous().to(device)
 
 
-def rope_inplace(x, cos_sin, S, heads, hd, nsec, direction=1):
+def rope_inplace(x, cos_sin, S, heads, hd, nsec, direction=1, positions=None):
+    """positions (int32 [rows], packed batches): explicit position of every token row; default row % S."""
     rows = x.shape[0]
-    lib.call("rv_rope_inplace", x, x.stride(0), cos_sin, rows, S, heads, hd, nsec, direction)
+    if positions is not None:
+        lib.call("rv_rope_inplace_pos", x, x.stride(0), cos_sin, positions, rows, heads, hd, nsec, direction)
+    else:
+        lib.call("rv_rope_inplace", x, x.stride(0), cos_sin, rows, S, heads, hd, nsec, direction)
     return x
 
 
-def attn_fwd(q, k, vT, B, S, H, hd, s_pad, causal, lens=None, scale=None, out=None, lse=None, kv_heads=None):
+def attn_fwd(q, k, vT, B, S, H, hd, s_pad, causal, lens=None, scale=None, out=None, lse=None, kv_heads=None, cu=None):
     """q, k: token-major [(B*S), H*hd] / [(B*S), kv_heads*hd] views; vT [B,kv_heads,hd,s_pad].
     Returns (out [(B*S), H*hd], lse fp32 [B,H,s_pad])."""
     scale = scale if scale is not None else 1.0 / math.sqrt(hd)
     Hkv = kv_heads or H
     if out is None:
-        out = torch.empty(B * S, H * hd, dtype=BF16, device=q.device)
+        out = torch.empty(q.shape[0], H * hd, dtype=BF16, device=q.device)
     if lse is None:
         lse = torch.zeros(B, H, s_pad, dtype=torch.float32, device=q.device)
-    lib.call("rv_attn_fwd_gqa", q, q.stride(0), k, k.stride(0), vT, out, out.stride(0), lse, lens, B, H, Hkv, S, s_pad, hd,
+    lib.call("rv_attn_fwd_gqa", q, q.stride(0), k, k.stride(0), vT, out, out.stride(0), lse, lens, cu, B, H, Hkv, S, s_pad, hd,
              int(causal), scale, lib.zeros16(q.device))
     return out, lse
 
 
 def attn_bwd(q, k, v, o, dout, lse, B, S, H, hd, s_pad, causal, lens=None, scale=None, dq=None, dk=None, dv=None,
-             kv_heads=None, use_workspace=True):
+             kv_heads=None, use_workspace=True, cu=None):
     scale = scale if scale is not None else 1.0 / math.sqrt(hd)
     dev = q.device
     Hkv = kv_heads or H
-    qT = transpose_heads(q, B, S, H, hd, s_pad)
-    kT = transpose_heads(k, B, S, Hkv, hd, s_pad)
-    doT = transpose_heads(dout, B, S, H, hd, s_pad)
+    rows = q.shape[0]                       # B*S, or the packed row count cu[B]
+    qT = transpose_heads(q, B, S, H, hd, s_pad, cu=cu)
+    kT = transpose_heads(k, B, S, Hkv, hd, s_pad, cu=cu)
+    doT = transpose_heads(dout, B, S, H, hd, s_pad, cu=cu)
     delta = torch.zeros(B, H, s_pad, dtype=torch.float32, device=dev)
-    dq = torch.empty(B * S, H * hd, dtype=BF16, device=dev) if dq is None else dq
-    dk = torch.empty(B * S, Hkv * hd, dtype=BF16, device=dev) if dk is None else dk
-    dv = torch.empty(B * S, Hkv * hd, dtype=BF16, device=dev) if dv is None else dv
+    dq = torch.empty(rows, H * hd, dtype=BF16, device=dev) if dq is None else dq
+    dk = torch.empty(rows, Hkv * hd, dtype=BF16, device=dev) if dk is None else dk
+    dv = torch.empty(rows, Hkv * hd, dtype=BF16, device=dev) if dv is None else dv
     # per-query-head dK/dV partials for the small-grid grouped-query case (the C side decides whether to use it)
-    ws = torch.empty(2 * B * S * H * hd, dtype=BF16, device=dev) if (Hkv != H and use_workspace) else None
+    ws = torch.empty(2 * rows * H * hd, dtype=BF16, device=dev) if (Hkv != H and use_workspace) else None
     lib.call("rv_attn_bwd_gqa", q, q.stride(0), k, k.stride(0), v, v.stride(0), o, o.stride(0), dout, dout.stride(0), qT, kT, doT,
-             lse, delta, dq, dq.stride(0), dk, dk.stride(0), dv, dv.stride(0), lens, B, H, Hkv, S, s_pad, hd, int(causal), scale,
+             lse, delta, dq, dq.stride(0), dk, dk.stride(0), dv, dv.stride(0), lens, cu, rows if cu is not None else 0, B, H, Hkv, S,
+             s_pad, hd, int(causal), scale,
              ws, ws.numel() * ws.element_size() if ws is not None else 0, lib.zeros16(dev))
     return dq, dk, dv
 

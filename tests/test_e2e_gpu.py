@@ -71,9 +71,11 @@ def _check(eng, g, meta, loss, logits, plan, full=True, loss_tol=5e-3):
     return worst
 
 
-def test_toy_forward_backward(golden_dir):
+@pytest.mark.parametrize("packed", [False, True])
+def test_toy_forward_backward(golden_dir, packed):
+    """packed=True: the decoder runs on sum(len) token rows (varlen attention, explicit rope positions), SURVEY 8f.2."""
     g, meta, images = _golden(golden_dir, "toy_e2e")
-    eng = _engine("toy")
+    eng = _engine("toy", packed=packed)
     loss, logits, plan = _run(eng, g, images)
     _check(eng, g, meta, loss, logits, plan)
     # image features (tower + projector) against the reference
@@ -104,7 +106,8 @@ def test_toy_vision_tower_tunable(golden_dir):
 def _check_slices(eng, g, logits, images):
     ref = torch.from_numpy(g["logits_slice"])
     got = logits[:, ::7, ::997]
-    assert float((got - ref).abs().max() / float(g["logits_absmax"].max())) < 3e-2
+    m = torch.from_numpy(g["splice_attention_mask"])[:, ::7]      # padding rows carry no defined logits in packed batches
+    assert float((got - ref)[m].abs().max() / float(g["logits_absmax"].max())) < 3e-2
 
 
 def test_toy_qwen2_siglip(golden_dir):
@@ -120,15 +123,17 @@ def test_toy_qwen2_siglip(golden_dir):
     assert float((tab[:-1, ::37].float().cpu() - ref).abs().max() / ref.abs().max()) < 3e-2
 
 
-def test_toy_qwen2_anyres_max_tower_tunable(golden_dir):
+@pytest.mark.parametrize("packed", [False, True])
+def test_toy_qwen2_anyres_max_tower_tunable(golden_dir, packed):
     """The RadVLM recipe shape (finetune_radio_7b.sh): anyres_max_N + spatial_unpad (bilinear down-sampling of the unpadded
     grid, llava_arch.py:381-392) with the SigLIP tower tunable -> tower backward through padded heads."""
     g, meta, images = _golden(golden_dir, "toy_qwen_anyres_max_e2e")
     eng = _engine("toy_qwen", merge_type=meta["merge_type"], image_aspect_ratio=meta["aspect"], image_grid_pinpoints=meta["pinpoints"],
-                  train_vision_tower=True)
+                  train_vision_tower=True, packed=packed)
     sizes = [tuple(s) for s in g["image_sizes"].tolist()]
     loss, logits, plan = _run(eng, g, images, sizes)
     assert plan["n_extra_rows"] == 38 * 38
+    assert plan["idx"].shape[0] == (int(g["splice_attention_mask"].sum()) if packed else g["splice_attention_mask"].size)
     _check(eng, g, meta, loss, logits, plan, full=False)
     _check_slices(eng, g, logits, images)
     eng.optimizer_step(lr=1e-3, max_grad_norm=1.0, mm_vision_tower_lr=2e-4)

@@ -259,6 +259,51 @@ def test_attention_gqa(ops, B, S, H, Hkv, hd, lens):
                 assert float(got[~vk].abs().max()) == 0.0, (name, use_ws)
 
 
+@pytest.mark.parametrize("H,Hkv,hd,lens", [(2, 2, 64, [130, 7, 64]), (4, 2, 128, [300, 129]), (6, 1, 128, [70, 33, 1])])
+def test_attention_packed_varlen(ops, H, Hkv, hd, lens):
+    """Packed batches: samples of different length stored back to back (cu_rows), no padding rows; every sample
+    must equal the oracle's attention on that sample alone, and no kernel may touch a neighbour's rows."""
+    from oracle import llava_oracle as O
+    B, S = len(lens), max(lens)
+    d, kvd = H * hd, Hkv * hd
+    s_pad = (S + 63) // 64 * 64
+    M = sum(lens)
+    qkv = rnd(140, (M, d + 2 * kvd), 1.0)
+    dout = rnd(141, (M, d), 1.0)
+    cu_h = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    cu = torch.from_numpy(cu_h).cuda()
+    g = qkv.cuda()
+    gq, gk, gv = g[:, :d], g[:, d:d + kvd], g[:, d + kvd:]
+    vT = ops.transpose_heads(gv, B, S, Hkv, hd, s_pad, cu=cu)
+    out, lse = ops.attn_fwd(gq, gk, vT, B, S, H, hd, s_pad, True, kv_heads=Hkv, cu=cu)
+    assert out.shape == (M, d)
+    res = {}
+    for use_ws in (False, True):
+        res[use_ws] = ops.attn_bwd(gq, gk, gv, out, dout.cuda(), lse, B, S, H, hd, s_pad, True, kv_heads=Hkv, cu=cu, use_workspace=use_ws)
+    rep = H // Hkv
+    for b, L in enumerate(lens):
+        r0, r1 = int(cu_h[b]), int(cu_h[b + 1])
+        q = qkv[r0:r1, :d].float().view(1, L, H, hd).transpose(1, 2).requires_grad_(True)
+        k = qkv[r0:r1, d:d + kvd].float().view(1, L, Hkv, hd).transpose(1, 2).requires_grad_(True)
+        v = qkv[r0:r1, d + kvd:].float().view(1, L, Hkv, hd).transpose(1, 2).requires_grad_(True)
+        ref = O.attention(q, k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1), causal=True)
+        ref.backward(dout[r0:r1].float().view(1, L, H, hd).transpose(1, 2))
+        got = out[r0:r1].cpu().float().view(1, L, H, hd).transpose(1, 2)
+        assert relerr(got, ref.detach()) < TOL, ("out", b)
+        for use_ws, (dq, dk, dv) in res.items():
+            gdq = dq[r0:r1].cpu().float().view(1, L, H, hd).transpose(1, 2)
+            if L == 1:   # one key: softmax == 1 exactly, so dq is mathematically zero (bf16 arithmetic leaves ~1e-7)
+                assert float(gdq.abs().max()) < 1e-5 and float(q.grad.abs().max()) < 1e-6
+            else:
+                assert relerr(gdq, q.grad) < 2 * TOL, ("dq", b, use_ws)
+            gdk = dk[r0:r1].cpu().float().view(1, L, Hkv, hd).transpose(1, 2)
+            if L == 1:
+                assert float(gdk.abs().max()) < 1e-5 and float(k.grad.abs().max()) < 1e-6
+            else:
+                assert relerr(gdk, k.grad) < 2 * TOL, ("dk", b, use_ws)
+            assert relerr(dv[r0:r1].cpu().float().view(1, L, Hkv, hd).transpose(1, 2), v.grad) < 2 * TOL, ("dv", b, use_ws)
+
+
 def test_gelu_tanh_and_weighted_rows(ops):
     import torch.nn.functional as F
     x, dy = rnd(130, (37, 200), 2.0), rnd(131, (37, 200), 1.0)
