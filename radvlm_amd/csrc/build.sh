@@ -1,15 +1,22 @@
 #!/bin/bash
 # Build libradvlm_hip.so (gfx950) in-tree. hipcc cross-compiles without a GPU.
+# The compiler's per-kernel resource report is kept (build/*.res) and the build FAILS if a hot kernel (GEMM, attention) touches
+# scratch memory: a rolled epilogue loop once turned the GEMM accumulators into a scratch array and cost 18 % unnoticed.
 set -e
 cd "$(dirname "$0")"
 OUT=../libradvlm_hip.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I. -I../../include -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I. -I../../include -Wno-unused-result -Rpass-analysis=kernel-resource-usage"
 mkdir -p build
 pids=()
 for f in gemm_bf16 attention ops; do
-  ( hipcc $FLAGS -c $f.hip -o build/$f.o ) &
+  ( hipcc $FLAGS -c $f.hip -o build/$f.o 2> build/$f.res || { cat build/$f.res >&2; exit 1; } ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
+grep -h "error\|warning" build/*.res | grep -v "Rpass" | head -20 || true
+if grep -h -B8 "ScratchSize \[bytes/lane\]: [1-9]" build/gemm_bf16.res build/attention.res | grep "Function Name"; then
+  echo "ERROR: the kernels above use scratch memory (see build/*.res)" >&2
+  exit 1
+fi
 hipcc --offload-arch=gfx950 -shared -fPIC build/gemm_bf16.o build/attention.o build/ops.o -o $OUT
 echo "built $OUT"

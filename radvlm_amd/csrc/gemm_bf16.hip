@@ -11,6 +11,7 @@
 // ds_read_b128 fragment reads are bank-conflict free, XCD-aware + grouped block->tile map.
 // Edge handling: out-of-range rows / k-chunks are sourced from a 16-byte zero page (per-lane source select),
 // so any M, N and any K % 8 == 0 work; stores are masked.
+#include <type_traits>
 #include "common.h"
 #include "radvlm_hip.h"
 #include <stdlib.h>
@@ -35,10 +36,23 @@ struct GemmParams {
     int n_full;
 };
 
+// Epilogue activations, kept to a few straight-line instructions each: the epilogue is unrolled 16 x 8 times and inlining libm's
+// erff / tanhf there pushed it past LLVM's pragma-unroll threshold -- the loops over the accumulator tile were then left
+// rolled, the 128 accumulator registers became a dynamically indexed scratch array (528 B/lane) and every GEMM ran ~18 % slower
+// (build.sh now fails on any kernel that uses scratch).
+//   erf GELU  : erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 / fp32-accumulate noise of the output)
+//   tanh GELU : 0.5 x (1 + tanh u) == x * sigmoid(2u)  (exact identity), u = sqrt(2/pi) (x + 0.044715 x^3)
+DEVINL float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(1.f + 0.3275911f * ax);
+    const float p = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float r = 1.f - p * __expf(-ax * ax);
+    return copysignf(r, x);
+}
 DEVINL float apply_act(float x, int act) {
     if (act == RV_ACT_QUICK_GELU) return x / (1.f + __expf(-1.702f * x));
-    if (act == RV_ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
-    if (act == RV_ACT_GELU_TANH) return 0.5f * x * (1.f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+    if (act == RV_ACT_GELU) return 0.5f * x * (1.f + erf_as(x * 0.70710678118654752f));
+    if (act == RV_ACT_GELU_TANH) return x / (1.f + __expf(-1.5957691216057308f * (x + 0.044715f * x * x * x)));
     return x;
 }
 
@@ -347,86 +361,110 @@ DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int br
     __builtin_amdgcn_s_setprio(0);
 }
 
+// Compile-time loop: the body is instantiated once per index, so accumulator registers are always addressed statically (a
+// `#pragma unroll` loop is only a request: when the optimiser declined it, acc[i][..] became a scratch array).
+template <int N, class F>
+DEVINL void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
 template <int MODE>
 DEVINL void epilogue_256(const f32x4 (&acc)[8][4], const GemmParams& P, int m0, int n0, int wr, int wc, int lane, int kslice) {
     // epilogue: with the interleaved B rows a lane holds, for m = m0 + wr*128 + i*16 + (lane&15), the 8 consecutive columns
     // n = n0 + wc*64 + 32a + 8*(lane>>4) + {0..7}: acc[i][2a][0..3] then acc[i][2a+1][0..3]
     const bool n_vec_ok = (P.N % 8 == 0) && (P.ldc % 8 == 0) && (!P.R || P.ldr % 8 == 0) &&
                           ((((uintptr_t)P.C) | ((uintptr_t)P.R) | ((uintptr_t)P.bias)) & 15) == 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    static_for<16>([&](auto ia) {
+        constexpr int i = decltype(ia)::value >> 1, a = decltype(ia)::value & 1;
         const int m = m0 + wr * 128 + i * 16 + (lane & 15);
-        if (m >= P.M) continue;
+        const int n = n0 + wc * 64 + 32 * a + 8 * (lane >> 4);
+        if (m >= P.M || n >= P.N) return;
+        const f32x4 lo = acc[i][2 * a], hi = acc[i][2 * a + 1];
+        if (MODE == 2) {   // raw partial sums; alpha / bias / act / residual are applied by the reduce kernel
+            float* wp = P.ws + ((long)kslice * P.M + m) * P.N + n;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int n = n0 + wc * 64 + 32 * a + 8 * (lane >> 4);
-            if (n >= P.N) continue;
-            float v[8];
-            if (MODE == 2) {   // raw partial sums; alpha / bias / act / residual are applied by the reduce kernel
-                float* wp = P.ws + ((long)kslice * P.M + m) * P.N + n;
+            for (int r = 0; r < 4; ++r) { if (n + r < P.N) wp[r] = lo[r]; if (n + 4 + r < P.N) wp[4 + r] = hi[r]; }
+            return;
+        }
+        float v[8] = {lo[0] * P.alpha, lo[1] * P.alpha, lo[2] * P.alpha, lo[3] * P.alpha,
+                      hi[0] * P.alpha, hi[1] * P.alpha, hi[2] * P.alpha, hi[3] * P.alpha};
+        const int nv = min(8, P.N - n);
+        const bool full = (nv == 8) && n_vec_ok;
+        if (P.bias) {
+            if (full) {
+                const bf16x8 bb = *(const bf16x8*)(P.bias + n);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { if (n + r < P.N) wp[r] = acc[i][2 * a][r]; if (n + 4 + r < P.N) wp[4 + r] = acc[i][2 * a + 1][r]; }
-                continue;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * a][r] * P.alpha; v[4 + r] = acc[i][2 * a + 1][r] * P.alpha; }
-            const int nv = min(8, P.N - n);
-            const bool full = (nv == 8) && n_vec_ok;
-            if (P.bias) {
-                if (full) {
-                    const bf16x8 bb = *(const bf16x8*)(P.bias + n);
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] += bf2f(bb[r]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) if (r < nv) v[r] += bf2f(P.bias[n + r]);
-                }
-            }
-            if (P.act != RV_ACT_NONE) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = apply_act(v[r], P.act);
-            }
-            if (P.R) {
-                if (P.res_f32) {
-                    const float* rp = (const float*)P.R + (long)m * P.ldr + n;
-                    if (full) {
-                        const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) if (r < nv) v[r] += rp[r];
-                    }
-                } else {
-                    const bf16* rp = (const bf16*)P.R + (long)m * P.ldr + n;
-                    if (full) {
-                        const bf16x8 rr = *(const bf16x8*)rp;
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] += bf2f(rr[r]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) if (r < nv) v[r] += bf2f(rp[r]);
-                    }
-                }
-            }
-            if (P.out_f32) {
-                float* cp = (float*)P.C + (long)m * P.ldc + n;
-                if (full) { *(f32x4*)cp = f32x4{v[0], v[1], v[2], v[3]}; *(f32x4*)(cp + 4) = f32x4{v[4], v[5], v[6], v[7]}; }
-                else for (int r = 0; r < nv; ++r) cp[r] = v[r];
+                for (int r = 0; r < 8; ++r) v[r] += bf2f(bb[r]);
             } else {
-                bf16* cp = (bf16*)P.C + (long)m * P.ldc + n;
-                if (full) *(bf16x8*)cp = bf16x8{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3]), f2bf(v[4]), f2bf(v[5]), f2bf(v[6]), f2bf(v[7])};
-                else for (int r = 0; r < nv; ++r) cp[r] = f2bf(v[r]);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) if (r < nv) v[r] += bf2f(P.bias[n + r]);
             }
         }
-    }
+        if (P.act != RV_ACT_NONE) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = apply_act(v[r], P.act);
+        }
+        if (P.R) {
+            if (P.res_f32) {
+                const float* rp = (const float*)P.R + (long)m * P.ldr + n;
+                if (full) {
+                    const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] += r0[r]; v[4 + r] += r1[r]; }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) if (r < nv) v[r] += rp[r];
+                }
+            } else {
+                const bf16* rp = (const bf16*)P.R + (long)m * P.ldr + n;
+                if (full) {
+                    const bf16x8 rr = *(const bf16x8*)rp;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += bf2f(rr[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) if (r < nv) v[r] += bf2f(rp[r]);
+                }
+            }
+        }
+        if (P.out_f32) {
+            float* cp = (float*)P.C + (long)m * P.ldc + n;
+            if (full) { *(f32x4*)cp = f32x4{v[0], v[1], v[2], v[3]}; *(f32x4*)(cp + 4) = f32x4{v[4], v[5], v[6], v[7]}; }
+            else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) if (r < nv) cp[r] = v[r];
+            }
+        } else {
+            bf16* cp = (bf16*)P.C + (long)m * P.ldc + n;
+            if (full) *(bf16x8*)cp = bf16x8{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3]), f2bf(v[4]), f2bf(v[5]), f2bf(v[6]), f2bf(v[7])};
+            else {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) if (r < nv) cp[r] = f2bf(v[r]);
+            }
+        }
+    });
 }
+
+#ifdef RV_STAMPS
+// Diagnostic build only (tools/gemm_stamps.py): wall-clock stamps (s_memrealtime, 100 MHz) of wave 0 of every block at kernel
+// entry, first MFMA-ready barrier, end of the K loop and end of the epilogue (after its stores are acknowledged) -> a buffer
+// no product code reads.  The buffer pointer rides the kernarg segment (P.ws, unused by MODE 0): no vector load, no extra wait.
+static long long* g_stamp_host = nullptr;
+extern "C" int rv_debug_set_stamp_buffer(void* p) { g_stamp_host = (long long*)p; return 0; }
+#define RV_STAMP(i) do { if (MODE == 0 && P.ws && threadIdx.x == 0) ((long long*)P.ws)[(long)blockIdx.x * 4 + (i)] = wall_clock64(); } while (0)
+#else
+#define RV_STAMP(i) do { } while (0)
+#endif
 
 template <bool TA, bool TB, int MODE>
 __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wid = wave_id(), lane = lane_id();
     const int wr = wid >> 2, wc = wid & 3;
+    RV_STAMP(0);
 
     const int nwg = P.tiles_m * P.tiles_n;
     int vtile = blockIdx.x, kslice = 0;
@@ -472,6 +510,7 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
     if (nt > 1) { stageA(1, 1, 0); stageA(1, 1, 1); stageB(1, 0); stageB(1, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    RV_STAMP(1);
 
     int aslot = 0;          // A ring slot of tile t (t % 3)
     for (int t = 0; t < nt; ++t) {
@@ -489,6 +528,7 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
         BAR_LGKM();   // also: every wave's A reads of tile t are complete -> the A halves of this slot may be restaged
     }
 
+    RV_STAMP(2);
     if (MODE == 3 && sliced) {
         // raw fp32 partial tile, tile-local [256][256] layout: slab = (tail tile index) * splits + kslice
         float* slab = P.ws + ((long)(vtile - P.n_full) * P.splits + kslice) * (BM2 * BN2);
@@ -503,6 +543,10 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
         return;
     }
     epilogue_256<MODE == 3 ? 0 : MODE>(acc, P, m0, n0, wr, wc, lane, kslice);
+#ifdef RV_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    RV_STAMP(3);
 }
 
 // C = act(alpha * sum_s ws[s] + bias) + residual  (finishes a split-K GEMM)
@@ -641,6 +685,9 @@ extern "C" int rv_gemm_bf16_ex(const void* A, int64_t lda, const void* B, int64_
     const bool use256 = (trans_a || trans_b || mode) ? true : (force ? (force == 2) : (cost256 <= cost128));
     hipStream_t st = (hipStream_t)stream;
     if (use256) {
+#ifdef RV_STAMPS
+        if (mode == 0) P.ws = (float*)g_stamp_host;
+#endif
         P.tiles_m = (M + BM2 - 1) / BM2; P.tiles_n = (N + BN2 - 1) / BN2;
         if (trans_a) { if (trans_b) launch256<true, true>(P, mode, st); else launch256<true, false>(P, mode, st); }
         else { if (trans_b) launch256<false, true>(P, mode, st); else launch256<false, false>(P, mode, st); }
