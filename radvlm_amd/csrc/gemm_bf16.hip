@@ -268,53 +268,145 @@ DEVINL bf16x8 frag_get(const Frag& f) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
+// Compile-time loop: the body is instantiated once per index, so accumulator registers are always addressed statically (a
+// `#pragma unroll` loop is only a request: when the optimiser declined it, acc[i][..] became a scratch array).
+template <int N, class F>
+DEVINL void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+
+// Row-major (non-transposed) fragments issued from inline asm with an immediate offset, for the phase whose reads must be
+// retired in two steps: hipcc's own waitcnt insertion put one `s_waitcnt lgkmcnt(0)` in front of phase 1's first MFMA, i.e.
+// waited for all 16 reads of the phase (incl. the B(nh1) prefetch) -- ~500 LDS cycles with every wave reading at once.
+DEVINL unsigned frag_base(const char* tile, int row0, int kk, int lane) {
+    const int r = lane & 15;                       // row0 % 16 == 0: the swizzle term depends on the lane only
+    const int p = (kk * 4 + (lane >> 4)) ^ ((r >> 1) & 7);
+    const char* a = tile + (row0 + r) * 128 + p * 16;
+    return (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)a;
+}
+template <int IMM>
+DEVINL void frag_issue_imm(Frag& f, unsigned base) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.n) : "v"(base), "i"(IMM) : "memory");
+}
+// Counted waits that name the destinations of the asm-issued reads they retire (so no consumer is scheduled above them);
+// LEFT = younger LDS operations allowed to stay in flight (LDS operations return in order).
+template <bool T, int LEFT>
+DEVINL void fwait1(Frag& a) {
+    if constexpr (T) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a.t0), "+v"(a.t1) : "i"(LEFT) : "memory");
+    else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(a.n) : "i"(LEFT) : "memory");
+}
+template <bool T, int LEFT>
+DEVINL void fwait2(Frag& a, Frag& b) {
+    if constexpr (T) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a.t0), "+v"(a.t1), "+v"(b.t0), "+v"(b.t1) : "i"(LEFT) : "memory");
+    else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a.n), "+v"(b.n) : "i"(LEFT) : "memory");
+}
+template <bool T, int LEFT>
+DEVINL void fwait4(Frag& a, Frag& b, Frag& c, Frag& d) {
+    if constexpr (T) asm volatile("s_waitcnt lgkmcnt(%8)"
+                                  : "+v"(a.t0), "+v"(a.t1), "+v"(b.t0), "+v"(b.t1), "+v"(c.t0), "+v"(c.t1), "+v"(d.t0), "+v"(d.t1) : "i"(LEFT) : "memory");
+    else asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a.n), "+v"(b.n), "+v"(c.n), "+v"(d.n) : "i"(LEFT) : "memory");
+}
+// One fragment read, either operand form: FOFF = feature-row offset (compile time) from `rowbase`; row-major operands use the
+// per-k-step base address + an immediate, transposed ones the tr-read pair of frag_issue.
+template <bool T, bool PERM, int FOFF>
+DEVINL void fissue(Frag& f, const char* tile, unsigned base_rowmajor, int rowbase, int kk, int lane) {
+    if constexpr (T) frag_issue<true, PERM>(f, tile, rowbase + FOFF, kk, lane);
+    else frag_issue_imm<FOFF * 128>(f, base_rowmajor);
+}
+
 #define BAR_LGKM() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifdef RV_STAMPS
+// diagnostic build: cycles wave 0 spends parked at the mid-tile barrier [0], the end-of-tile vmcnt wait [1] and barrier [2]
+#define RV_ACC_BEGIN() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg[3] = __builtin_readcyclecounter(); } while (0)
+#define RV_ACC_END(k) do { asm volatile("" ::: "memory"); dbg[k] += __builtin_readcyclecounter() - dbg[3]; } while (0)
+#else
+#define RV_ACC_BEGIN() do { } while (0)
+#define RV_ACC_END(k) do { } while (0)
+#endif
 
 // One K-tile step of the 256x256 kernel (4 phases x 16 MFMAs per wave); ph1..ph4 issue this step's LDS-DMA staging.
 template <bool TA, bool TB, class F1, class F2, class F3, class F4>
-DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int brow0, int lane, F1 ph1, F2 ph2, F3 ph3, F4 ph4) {
+DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int brow0, int lane, F1 ph1, F2 ph2, F3 ph3, F4 ph4,
+                      long long (&dbg)[4]) {
     Frag fa[4][2], fb[2][2][2];
     bf16x8 a[4][2], b[2][2][2];
+    constexpr int OA = TA ? 2 : 1, OB = TB ? 2 : 1;      // LDS operations per fragment (tr reads come in pairs)
+    constexpr int G = 2 * OB + 4 * OA, B1_OPS = 4 * OB;   // one k-step group of phase 1 (B(nh0) x2 + A(mh0) x4); the B(nh1) prefetch
+    constexpr int W0 = G + B1_OPS > 15 ? 15 : G + B1_OPS;   // lgkmcnt is a 4-bit count: a larger allowance is clamped (waits for a little more)
+    const unsigned ab[2] = {TA ? 0u : frag_base(At, 0, 0, lane), TA ? 0u : frag_base(At, 0, 1, lane)};
+    const unsigned bb[2] = {TB ? 0u : frag_base(Bt, brow0, 0, lane), TB ? 0u : frag_base(Bt, brow0, 1, lane)};
 
-    // ---- phase 1: read A(mh0), B(nh0) and, ahead of time, B(nh1)
+    // ---- phase 1: read A(mh0), B(nh0) and, ahead of time, B(nh1).  Every read is issued from asm and retired by counted
+    // waits: the k-step-0 MFMAs start as soon as THEIR six fragments are back, the k-step-1 MFMAs after the next six, and
+    // the B(nh1) prefetch stays in flight behind both (hipcc's own bookkeeping waited for all 16 reads before the first MFMA).
     ph1();
+    // issue order inside a k-step group: B0, A0, B1, A1, A2, A3 -- the first MFMA needs only the first two fragments
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) frag_issue<TB, true>(fb[0][j][kk], Bt, brow0 + j * 16, kk, lane);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) frag_issue<TA>(fa[i][kk], At, i * 16, kk, lane);
+        fissue<TB, true, 0>(fb[0][0][kk], Bt, bb[kk], brow0, kk, lane);
+        fissue<TA, false, 0>(fa[0][kk], At, ab[kk], 0, kk, lane);
+        fissue<TB, true, 16>(fb[0][1][kk], Bt, bb[kk], brow0, kk, lane);
+        fissue<TA, false, 16>(fa[1][kk], At, ab[kk], 0, kk, lane);
+        fissue<TA, false, 32>(fa[2][kk], At, ab[kk], 0, kk, lane);
+        fissue<TA, false, 48>(fa[3][kk], At, ab[kk], 0, kk, lane);
     }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) frag_issue<TB, true>(fb[1][j][kk], Bt, brow0 + 32 + j * 16, kk, lane);
-    constexpr int B1_OPS = TB ? 8 : 4;   // the B(nh1) prefetch stays in flight behind phase 1's MFMAs
-    frag_wait4<TB, B1_OPS>(fb[0][0][0], fb[0][1][0], fb[0][0][1], fb[0][1][1]);
-    frag_wait4<TA, B1_OPS>(fa[0][0], fa[1][0], fa[2][0], fa[3][0]);
-    frag_wait4<TA, B1_OPS>(fa[0][1], fa[1][1], fa[2][1], fa[3][1]);
-    if (TA || TB) __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) b[0][j][kk] = frag_get<TB>(fb[0][j][kk]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i][kk] = frag_get<TA>(fa[i][kk]);
-    }
+        static_for<2>([&](auto j) { fissue<TB, true, 32 + decltype(j)::value * 16>(fb[1][decltype(j)::value][kk], Bt, bb[kk], brow0, kk, lane); });
     __builtin_amdgcn_s_setprio(1);
+    // k-step 0 streams: each wait retires one more fragment (younger reads stay in flight) and releases the MFMAs it completes
+    constexpr int R = G + B1_OPS;
+#define RV_C15(x) ((x) > 15 ? 15 : (x))
+    fwait1<TB, RV_C15(OB + 3 * OA + R)>(fb[0][0][0]);
+    fwait1<TA, RV_C15(OB + 3 * OA + R)>(fa[0][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    b[0][0][0] = frag_get<TB>(fb[0][0][0]); a[0][0] = frag_get<TA>(fa[0][0]);
+    acc[0][0] = mfma16(b[0][0][0], a[0][0], acc[0][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    fwait1<TB, RV_C15(3 * OA + R)>(fb[0][1][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    b[0][1][0] = frag_get<TB>(fb[0][1][0]);
+    acc[0][1] = mfma16(b[0][1][0], a[0][0], acc[0][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    fwait1<TA, RV_C15(2 * OA + R)>(fa[1][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    a[1][0] = frag_get<TA>(fa[1][0]);
+    acc[1][0] = mfma16(b[0][0][0], a[1][0], acc[1][0]); acc[1][1] = mfma16(b[0][1][0], a[1][0], acc[1][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    fwait1<TA, RV_C15(OA + R)>(fa[2][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    a[2][0] = frag_get<TA>(fa[2][0]);
+    acc[2][0] = mfma16(b[0][0][0], a[2][0], acc[2][0]); acc[2][1] = mfma16(b[0][1][0], a[2][0], acc[2][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    fwait1<TA, RV_C15(R)>(fa[3][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    a[3][0] = frag_get<TA>(fa[3][0]);
+    acc[3][0] = mfma16(b[0][0][0], a[3][0], acc[3][0]); acc[3][1] = mfma16(b[0][1][0], a[3][0], acc[3][1]);
+#undef RV_C15
+    __builtin_amdgcn_sched_barrier(0);   // keep the k-step-0 MFMAs above the second wait
+    fwait2<TB, B1_OPS>(fb[0][0][1], fb[0][1][1]);
+    fwait4<TA, B1_OPS>(fa[0][1], fa[1][1], fa[2][1], fa[3][1]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    for (int j = 0; j < 2; ++j) b[0][j][1] = frag_get<TB>(fb[0][j][1]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) a[i][1] = frag_get<TA>(fa[i][1]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(b[0][j][kk], a[i][kk], acc[i][j]);
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(b[0][j][1], a[i][1], acc[i][j]);
     __builtin_amdgcn_s_setprio(0);
 
     // ---- phase 2: B(nh1) has landed behind phase 1's MFMAs; A(mh1) is read k-step by k-step behind this phase's MFMAs
     ph2();
+    RV_ACC_BEGIN();
     BAR_LGKM();   // every wave's B reads of tile t are complete -> the B slot of tile t may be restaged
-    frag_wait4<TB>(fb[1][0][0], fb[1][1][0], fb[1][0][1], fb[1][1][1]);
-    if (TB) __builtin_amdgcn_sched_barrier(0);
+    RV_ACC_END(0);
+    fwait4<TB, 0>(fb[1][0][0], fb[1][1][0], fb[1][0][1], fb[1][1][1]);   // already retired by the barrier's wait: pins the consumers below it
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -328,17 +420,16 @@ DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int br
             for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma16(b[1][j][kk], a[i][kk], acc[i][2 + j]);
         __builtin_amdgcn_s_setprio(0);
         // a[.][kk] is dead now: fetch A(mh1) for this k-step while the other k-step's MFMAs run
-#pragma unroll
-        for (int i = 0; i < 4; ++i) frag_issue<TA>(fa[i][kk], At, 64 + i * 16, kk, lane);
+        static_for<4>([&](auto i) { fissue<TA, false, 64 + decltype(i)::value * 16>(fa[decltype(i)::value][kk], At, ab[kk], 0, kk, lane); });
     }
 
     // ---- phase 3
     ph3();
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-        if (kk == 0) frag_wait4<TA, 8>(fa[0][0], fa[1][0], fa[2][0], fa[3][0]);   // the k-step-1 reads stay in flight
-        else frag_wait4<TA, 0>(fa[0][1], fa[1][1], fa[2][1], fa[3][1]);
-        if (TA) __builtin_amdgcn_sched_barrier(0);
+        if (kk == 0) fwait4<TA, 4 * OA>(fa[0][0], fa[1][0], fa[2][0], fa[3][0]);   // the k-step-1 reads stay in flight
+        else fwait4<TA, 0>(fa[0][1], fa[1][1], fa[2][1], fa[3][1]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i][kk] = frag_get<TA>(fa[i][kk]);
         __builtin_amdgcn_s_setprio(1);
@@ -359,16 +450,6 @@ DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int br
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[4 + i][j] = mfma16(b[0][j][kk], a[i][kk], acc[4 + i][j]);
     __builtin_amdgcn_s_setprio(0);
-}
-
-// Compile-time loop: the body is instantiated once per index, so accumulator registers are always addressed statically (a
-// `#pragma unroll` loop is only a request: when the optimiser declined it, acc[i][..] became a scratch array).
-template <int N, class F>
-DEVINL void static_for(F&& f) {
-    if constexpr (N > 0) {
-        static_for<N - 1>(f);
-        f(std::integral_constant<int, N - 1>{});
-    }
 }
 
 template <int MODE>
@@ -513,6 +594,7 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
     RV_STAMP(1);
 
     int aslot = 0;          // A ring slot of tile t (t % 3)
+    long long dbg[4] = {0, 0, 0, 0};   // diagnostic build only (RV_STAMPS): parked-cycle accumulators; dead code otherwise
     for (int t = 0; t < nt; ++t) {
         const char* At = smem + (aslot * 2 + wr) * HALF_BYTES;
         const char* Bt = smem + B_RING_OFF + ((t & 1) * 2 + (wc >> 1)) * HALF_BYTES;
@@ -520,13 +602,23 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
         const int brow0 = (wc & 1) * 64;
         ktile_256<TA, TB>(acc, At, Bt, brow0, lane,
                           [&]() { if (t + 2 < nt) stageA(t + 2, aslot2, 0); }, [&]() { if (t + 2 < nt) stageA(t + 2, aslot2, 1); },
-                          [&]() { if (t + 2 < nt) stageB(t + 2, 0); }, [&]() { if (t + 2 < nt) stageB(t + 2, 1); });
+                          [&]() { if (t + 2 < nt) stageB(t + 2, 0); }, [&]() { if (t + 2 < nt) stageB(t + 2, 1); }, dbg);
         // tile t+1 (issued during tile t-1) must have landed; the 8 loads of tile t+2 stay in flight
+        RV_ACC_BEGIN();
         if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RV_ACC_END(1);
         aslot = aslot == 2 ? 0 : aslot + 1;
+        RV_ACC_BEGIN();
         BAR_LGKM();   // also: every wave's A reads of tile t are complete -> the A halves of this slot may be restaged
+        RV_ACC_END(2);
     }
+#ifdef RV_STAMPS
+    if (MODE == 0 && P.ws && lane == 0) {   // per wave: [mid barrier, end vmcnt, end barrier] parked cycles of the whole K loop
+        long long* o = (long long*)P.ws + (long)gridDim.x * 4 + ((long)blockIdx.x * 8 + wid) * 3;
+        o[0] = dbg[0]; o[1] = dbg[1]; o[2] = dbg[2];
+    }
+#endif
 
     RV_STAMP(2);
     if (MODE == 3 && sliced) {

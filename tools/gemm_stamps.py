@@ -30,7 +30,7 @@ for name, m, n, k, ta, tb in [("qkv_fwd NT", T, 12288, 4096, 0, 0), ("o_fwd NT",
     b = torch.randn((k, n) if tb else (n, k), device="cuda", dtype=torch.bfloat16)
     c = torch.empty(m, n, device="cuda", dtype=torch.bfloat16)
     nblk = ((m + 255) // 256) * ((n + 255) // 256)
-    buf = torch.zeros(nblk * 4, dtype=torch.int64, device="cuda")
+    buf = torch.zeros(nblk * 4 + nblk * 8 * 3, dtype=torch.int64, device="cuda")
     def run():
         assert l.rv_gemm_bf16(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), c.data_ptr(), n, None, None, 0, m, n, k, ta, tb, 1.0, 0, 0, 0, z.data_ptr(), st) == 0
     l.rv_debug_set_stamp_buffer(None)
@@ -40,12 +40,17 @@ for name, m, n, k, ta, tb in [("qkv_fwd NT", T, 12288, 4096, 0, 0), ("o_fwd NT",
     run()
     torch.cuda.synchronize()
     l.rv_debug_set_stamp_buffer(None)
-    s = buf.view(nblk, 4).cpu().numpy().astype(np.float64) * 0.01          # us
+    s = buf[:nblk * 4].view(nblk, 4).cpu().numpy().astype(np.float64) * 0.01          # us
+    park = buf[nblk * 4:].view(nblk, 8, 3).cpu().numpy().astype(np.float64)   # shader cycles per wave over the K loop
     t0 = s[:, 0].min()
     pro, loop, epi = s[:, 1] - s[:, 0], s[:, 2] - s[:, 1], s[:, 3] - s[:, 2]
     first = np.argsort(s[:, 0])[:256]
     print(f"{name} {(m, n, k)}: {nblk} tiles, kernel {s[:, 3].max() - t0:.1f} us; per tile: prologue {pro.mean():.2f} (first round {pro[first].mean():.2f}, "
           f"later {np.delete(pro, first).mean():.2f}) loop {loop.mean():.2f} epilogue {epi.mean():.2f} us; total {(s[:, 3] - s[:, 0]).mean():.2f}", flush=True)
+    nt = (k + 63) // 64
+    pk = park.mean(axis=(0, 1)) / nt
+    print(f"    parked cycles per K-tile per wave: mid barrier(+own LDS reads) {pk[0]:.0f}, end-of-tile vmcnt {pk[1]:.0f}, end barrier {pk[2]:.0f}; "
+          f"loop = {loop.mean() / nt * 1e3:.0f} ns per K-tile", flush=True)
     # CU-slot idle gaps: sort block ends and starts; the i-th start after the first 256 follows the i-th end
     ends = np.sort(s[:, 3]); starts = np.sort(s[:, 0])[256:]
     if len(starts):
