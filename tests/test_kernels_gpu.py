@@ -522,3 +522,32 @@ def test_gemm_tail_split(ops, ta, tb):
     ref_rows = torch.cat([torch.arange(0, 300), torch.arange(4096, 4352)])   # head tiles and the last (tail) tile row
     ref = a[ref_rows].float() @ b.float().t()
     assert relerr(split_bf[ref_rows.cuda()], ref) < TOL
+
+
+def test_legacy_entry_points_match_the_extended_ones(ops):
+    """rv_gemm_nt_bf16 / rv_gemm_bf16 / rv_attn_fwd / rv_attn_bwd (the entries without scratch, grouped-query or packed-batch
+    arguments) forward to the extended ones: same bits on the same inputs."""
+    from radvlm_amd import lib
+    a, b, bias = rnd(150, (300, 192), 1.0).cuda(), rnd(151, (264, 192), 0.2).cuda(), rnd(152, (264,), 0.5).cuda()
+    want = ops.gemm(a, b, bias=bias, act=ops.ACT_QUICK_GELU)
+    assert torch.equal(ops._gemm_nt_direct(a, b, bias=bias, act=ops.ACT_QUICK_GELU), want)
+    c = torch.empty_like(want)
+    lib.call("rv_gemm_bf16", a, a.stride(0), b, b.stride(0), c, c.stride(0), bias, None, 0, 300, 264, 192, 0, 0, 1.0, ops.ACT_QUICK_GELU, 0, 0,
+             lib.zeros16(a.device))
+    assert torch.equal(c, want)
+    B, S, H, hd = 2, 130, 3, 64
+    d, s_pad = H * hd, 192
+    qkv, dout = rnd(153, (B * S, 3 * d), 1.0).cuda(), rnd(154, (B * S, d), 1.0).cuda()
+    q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    vT = ops.transpose_heads(v, B, S, H, hd, s_pad)
+    out, lse = ops.attn_fwd(q, k, vT, B, S, H, hd, s_pad, True)
+    out2, lse2 = torch.empty_like(out), torch.zeros_like(lse)
+    lib.call("rv_attn_fwd", q, q.stride(0), k, k.stride(0), vT, out2, out2.stride(0), lse2, None, B, H, S, s_pad, hd, 1, hd ** -0.5, lib.zeros16(q.device))
+    assert torch.equal(out, out2) and torch.equal(lse, lse2)
+    dq, dk, dv = ops.attn_bwd(q, k, v, out, dout, lse, B, S, H, hd, s_pad, True)
+    qT, kT, doT = (ops.transpose_heads(t, B, S, H, hd, s_pad) for t in (q, k, dout))
+    delta = torch.zeros(B, H, s_pad, dtype=torch.float32, device=q.device)
+    g = [torch.empty(B * S, d, dtype=torch.bfloat16, device=q.device) for _ in range(3)]
+    lib.call("rv_attn_bwd", q, q.stride(0), k, k.stride(0), v, v.stride(0), out, out.stride(0), dout, dout.stride(0), qT, kT, doT, lse, delta,
+             g[0], d, g[1], d, g[2], d, None, B, H, S, s_pad, hd, 1, hd ** -0.5, lib.zeros16(q.device))
+    assert torch.equal(g[0], dq) and torch.equal(g[1], dk) and torch.equal(g[2], dv)
