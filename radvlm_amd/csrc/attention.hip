@@ -58,6 +58,25 @@ template <int ROW_BYTES> DEVINL bf16x8 rd128(const char* tile, int row, int chun
 // The transposed global copies are written in MFMA contraction order (rv_transpose_bf16 perm32), so the 8 operands
 // kappa(g, 0..7) of a lane are the 16 contiguous bytes of chunk 4p + g: one conflict-free ds_read_b128.
 DEVINL bf16x8 rdT(const char* tile, int row, int p, int g) { return rd128<128>(tile, row, 4 * p + g); }
+// asm-issued fragment reads + counted waits (LDS operations return in order; LEFT = younger operations that may stay in
+// flight).  hipcc's own bookkeeping put an `s_waitcnt lgkmcnt(0)` right behind every compiler-visible ds_read in these loops
+// (one LDS round trip per pair of MFMAs); with the reads in asm a batch of four is fetched two batches ahead of its MFMAs.
+template <int ROW_BYTES> DEVINL void rd128_asm(bf16x8& dst, const char* tile, int row, int chunk) {
+    const char* a = tile + row * ROW_BYTES + ((chunk ^ swz<ROW_BYTES>(row)) << 4);
+    const unsigned o = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)a;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(o) : "memory");
+}
+template <int LEFT> DEVINL void lds_wait4(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(LEFT) : "memory");
+}
+template <int LEFT> DEVINL void lds_wait2(bf16x8& a, bf16x8& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "i"(LEFT) : "memory");
+}
+// wait for one batch of N (2 or 4) fragments
+template <int N, int LEFT> DEVINL void lds_wait(bf16x8 (&f)[N]) {
+    if constexpr (N == 4) lds_wait4<LEFT>(f[0], f[1], f[2], f[3]);
+    else lds_wait2<LEFT>(f[0], f[1]);
+}
 DEVINL bf16x8 pack8(f32x4 a, f32x4 b) {
     return bf16x8{f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
 }
@@ -123,14 +142,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
         for (int qs = 0; qs < 2; ++qs)
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) s[qs][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {   // S^T = K Q^T: the KS fragments of key block kb are one batch; batches kb+1, kb+2 are in flight while kb's MFMAs run
+            bf16x8 kq[3][KS];
+            auto issue_k = [&](int kb, bf16x8 (&dst)[KS]) {
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
+                for (int ks = 0; ks < KS; ++ks) rd128_asm<KROW>(dst[ks], Kt, kb * 16 + c, ks * 4 + g);
+            };
+            issue_k(0, kq[0]);
+            issue_k(1, kq[1]);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = rd128<KROW>(Kt, kb * 16 + c, ks * 4 + g);
+            for (int kb = 0; kb < 4; ++kb) {
+                if (kb + 2 < 4) issue_k(kb + 2, kq[(kb + 2) % 3]);
+                if (kb < 2) lds_wait<KS, 2 * KS>(kq[kb % 3]);
+                else if (kb == 2) lds_wait<KS, KS>(kq[kb % 3]);
+                else lds_wait<KS, 0>(kq[kb % 3]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int qs = 0; qs < 2; ++qs) s[qs][kb] = mfma16(kf, qf[qs][ks], s[qs][kb]);
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int qs = 0; qs < 2; ++qs) s[qs][kb] = mfma16(kq[kb % 3][ks], qf[qs][ks], s[qs][kb]);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        }
         // lane holds S^T[key = kv0 + 16kb + 4g + r][q = q0 + 16qs + c]
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
@@ -164,17 +197,35 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
 #pragma unroll
             for (int db = 0; db < DB; ++db) o[qs][db] *= alpha;
         }
-        // O^T[d][q] += V^T[d][key] P^T[key][q]
+        // O^T[d][q] += V^T[d][key] P^T[key][q]: V^T fragments in batches of four (db), two batches ahead of their MFMAs
+        {
+            bf16x8 vq[3][4];
+            constexpr int NB = 2 * DB / 4;     // batches over (kp, db)
+            auto issue_v = [&](int bi, bf16x8 (&dst)[4]) {
+                const int kp = bi / (DB / 4), db0 = (bi % (DB / 4)) * 4;
 #pragma unroll
-        for (int kp = 0; kp < 2; ++kp) {
-            bf16x8 pf[2];
+                for (int u = 0; u < 4; ++u) rd128_asm<128>(dst[u], Vt, (db0 + u) * 16 + c, 4 * kp + g);
+            };
+            issue_v(0, vq[0]);
+            issue_v(1, vq[1]);
+            bf16x8 pf[2][2];
 #pragma unroll
-            for (int qs = 0; qs < 2; ++qs) pf[qs] = pack8(s[qs][2 * kp], s[qs][2 * kp + 1]);
+            for (int kp = 0; kp < 2; ++kp)
 #pragma unroll
-            for (int db = 0; db < DB; ++db) {
-                const bf16x8 vf = rdT(Vt, db * 16 + c, kp, g);
+                for (int qs = 0; qs < 2; ++qs) pf[kp][qs] = pack8(s[qs][2 * kp], s[qs][2 * kp + 1]);
 #pragma unroll
-                for (int qs = 0; qs < 2; ++qs) o[qs][db] = mfma16(vf, pf[qs], o[qs][db]);
+            for (int bi = 0; bi < NB; ++bi) {
+                if (bi + 2 < NB) issue_v(bi + 2, vq[(bi + 2) % 3]);
+                if (bi + 2 < NB) lds_wait<4, 8>(vq[bi % 3]);
+                else if (bi + 1 < NB) lds_wait<4, 4>(vq[bi % 3]);
+                else lds_wait<4, 0>(vq[bi % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                const int kp = bi / (DB / 4), db0 = (bi % (DB / 4)) * 4;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int qs = 0; qs < 2; ++qs) o[qs][db0 + u] = mfma16(vq[bi % 3][u], pf[kp][qs], o[qs][db0 + u]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }

@@ -87,10 +87,11 @@ def load():
     """Load the shared library (no GPU needed to load); raises if it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            raise RadvlmHipError(f"{_LIB_PATH} not found: build it with radvlm_amd/csrc/build.sh "
+        path = os.environ.get("RADVLM_HIP_LIB", _LIB_PATH)     # override: A/B of two builds (tools/), never a fallback
+        if not os.path.exists(path):
+            raise RadvlmHipError(f"{path} not found: build it with radvlm_amd/csrc/build.sh "
                                  "(or __graft_entry__.build()); there is no CPU fallback")
-        lib = ctypes.CDLL(_LIB_PATH)
+        lib = ctypes.CDLL(path)
         lib.rv_version.restype = ctypes.c_char_p
         for name, sig in _SIGS.items():
             fn = getattr(lib, name)
