@@ -57,6 +57,9 @@ __global__ __launch_bounds__(TPB) void rmsnorm_fwd_kernel(const bf16* x, const b
 
 __global__ __launch_bounds__(TPB) void rmsnorm_bwd_kernel(const bf16* dy, const bf16* x, const bf16* w, const float* rstd,
                                                           bf16* dx, int dx_add, float* dw_partial, int rows, int d) {
+    // One row per block iteration; the NEXT row's three streams (x, dy and, when accumulating, dx) are fetched before this row's
+    // block-wide reduction, so two rows of loads are in flight per block (the reduction + its barriers used to sit between a row's
+    // loads and the next row's: 3.2 TB/s).
     __shared__ float red[4];
     float dw[4][8];
     float wv[4][8];
@@ -64,42 +67,46 @@ __global__ __launch_bounds__(TPB) void rmsnorm_bwd_kernel(const bf16* dy, const 
     for (int p = 0; p < 4; ++p) {
         const int e = (p * TPB + threadIdx.x) * 8;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dw[p][i] = 0.f;
+        for (int i = 0; i < 8; ++i) { dw[p][i] = 0.f; wv[p][i] = 0.f; }
         if (e < d) ld8(w + e, wv[p]);
     }
-    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
-        const float rs = rstd[row];
-        float xh[4][8], g[4][8];
-        float dot = 0.f;
+    const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 nx[4], ny[4], nd[4];
+    auto fetch = [&](long row) {
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int e = (p * TPB + threadIdx.x) * 8;
-            if (e < d) {
-                float xv[8], dv[8];
-                ld8(x + row * d + e, xv);
-                ld8(dy + row * d + e, dv);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    xh[p][i] = xv[i] * rs;
-                    g[p][i] = dv[i] * wv[p][i];
-                    dot += g[p][i] * xh[p][i];
-                    dw[p][i] += dv[i] * xh[p][i];
-                }
-            }
+            const bool ok = e < d && row < rows;
+            nx[p] = ok ? *(const bf16x8*)(x + row * d + e) : z8;
+            ny[p] = ok ? *(const bf16x8*)(dy + row * d + e) : z8;
+            nd[p] = (ok && dx_add) ? *(const bf16x8*)(dx + row * d + e) : z8;
         }
+    };
+    fetch(blockIdx.x);
+    for (long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float rs = rstd[row];
+        float xh[4][8], g[4][8], o[4][8];
+        float dot = 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float dv = bf2f(ny[p][i]);
+                xh[p][i] = bf2f(nx[p][i]) * rs;
+                g[p][i] = dv * wv[p][i];
+                dot += g[p][i] * xh[p][i];
+                dw[p][i] += dv * xh[p][i];
+                o[p][i] = bf2f(nd[p][i]);
+            }
+        fetch(row + gridDim.x);
         dot = block_sum<4>(dot, red) / (float)d;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const int e = (p * TPB + threadIdx.x) * 8;
             if (e < d) {
-                float o[8];
-                if (dx_add) ld8(dx + row * d + e, o);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float v = rs * (g[p][i] - xh[p][i] * dot);
-                    o[i] = dx_add ? o[i] + v : v;
-                }
-                st8(dx + row * d + e, o);
+                for (int i = 0; i < 8; ++i) o[p][i] += rs * (g[p][i] - xh[p][i] * dot);
+                st8(dx + row * d + e, o[p]);
             }
         }
     }

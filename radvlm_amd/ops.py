@@ -135,7 +135,7 @@ def rmsnorm_fwd(x, w, eps=1e-5, y=None, rstd=None):
 def rmsnorm_bwd(dy, x, w, rstd, dx=None, dx_add=False, dw=None, dw_accumulate=False):
     rows, d = x.shape
     assert dy.is_contiguous() and x.is_contiguous()
-    nblk = min(rows, 512)
+    nblk = min(rows, 1024)
     part = torch.empty(nblk, d, dtype=torch.float32, device=x.device)
     if dx is None:
         dx = torch.empty_like(x)
