@@ -507,3 +507,20 @@ def test_checkpoint_resume_is_bit_identical(golden_dir, tmp_path):
     # auto-resume picks the newest checkpoint: nothing left to do after checkpoint-4
     again, s_again = run(tmp_path / "a", 4, 0, True)
     assert s_again["global_step"] == 4 and torch.equal(again.engine.lm.flat, full.engine.lm.flat)
+
+
+@pytest.mark.parametrize("name,golden,kw", [("toy", "toy_e2e", {}), ("toy_qwen", "toy_qwen_e2e", {"train_vision_tower": True})])
+def test_training_reduces_the_loss(golden_dir, name, golden, kw):
+    """Forward + backward + AdamW really train: 25 steps on one fixed batch drive the loss far below its starting value (both model
+    flavours; the Qwen2/SigLIP one with the tower tunable), and every parameter stays finite."""
+    g, meta, images = _golden(golden_dir, golden)
+    eng = _engine(name, **kw)
+    losses = []
+    for _ in range(25):
+        loss = eng.forward(g["input_ids"], g["attention_mask"], g["labels"], images)
+        eng.backward()
+        eng.optimizer_step(lr=2e-3, weight_decay=0.0, max_grad_norm=1.0)
+        losses.append(float(loss))
+    assert abs(losses[0] - float(g["loss"])) < 5e-3
+    assert losses[-1] < 0.5 * losses[0], losses
+    assert all(np.isfinite(losses)) and bool(torch.isfinite(eng.lm.flat.float()).all())
