@@ -405,7 +405,7 @@ class LlavaEngine:
         pix = pix if pix.dtype == BF16 else ops.to_bf16(pix.float())
         ctx = dict(plan=plan)
         table = self.encode_images(pix.contiguous(), save=ctx, plan=plan)
-        B = len(images)
+        B = int(np.asarray(input_ids).shape[0])   # samples (a sample may hold several images: images are consumed in order)
         S = plan["S"]
         s_pad = _ru(S, 64)
         lens_np = plan["lens"]

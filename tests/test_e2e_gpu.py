@@ -524,3 +524,51 @@ def test_training_reduces_the_loss(golden_dir, name, golden, kw):
     assert abs(losses[0] - float(g["loss"])) < 5e-3
     assert losses[-1] < 0.5 * losses[0], losses
     assert all(np.isfinite(losses)) and bool(torch.isfinite(eng.lm.flat.float()).all())
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_edge_cases_against_oracle(packed):
+    """Edge cases of the splice (llava_arch.py:442-531) through the HIP engine vs the CPU oracle: an image placeholder at the
+    first and at the last position, two images in one sample, a text-only sample (consumes a dummy image, contributes no rows),
+    ragged lengths, and truncation at tokenizer_model_max_length that cuts through an image span."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import llava_oracle as O
+    from radvlm_amd.engine import LlavaEngine
+    geo = GEOMETRIES["toy"]
+    g = torch.Generator().manual_seed(11)
+    T = 14
+    ids = torch.randint(3, 1000, (4, T), generator=g)
+    labels = ids.clone()
+    mask = torch.ones(4, T, dtype=torch.bool)
+    ids[0, 0] = -200                               # image first
+    ids[1, 9] = -200; mask[1, 10:] = False         # image last (sample of 10 ids)
+    ids[2, 3] = -200; ids[2, 8] = -200             # two images in one sample
+    mask[3, 6:] = False                            # text only, short
+    labels[ids == -200] = -100
+    labels[:, :2] = -100
+    ids[~mask] = 0; labels[~mask] = -100
+    images = [torch.randn(3, 56, 56, generator=g).to(torch.bfloat16).float() for _ in range(4)] + [torch.zeros(3, 56, 56)]
+    # image slots are consumed in order: sample 0 -> img0, sample 1 -> img1, sample 2 -> img2 and img3, sample 3 (text) -> img4 (dummy)
+    max_len = 30                                    # sample 2 would be 12 + 2*16 = 44 rows: cut inside its second image
+    eng = LlavaEngine(geo, device="cuda:0", init="portable", seed=0, max_len=max_len, packed=packed)
+    loss = eng.forward(ids.numpy(), mask.numpy(), labels.numpy(), images, want_logits=True)
+    logits = eng.last_logits.cpu()
+    plan = eng.ctx["plan"]
+    eng.backward()
+    torch.cuda.synchronize()
+    P = O.make_params(geo, seed=0)
+    for k, v in P.items():
+        if "vision_tower" not in k:
+            v.requires_grad_(True)
+    rl, rlog, aux = O.llava_forward(P, geo, ids, mask, labels, images, cfg={"tokenizer_model_max_length": max_len})
+    rl.backward()
+    assert np.array_equal(plan["labels"], aux["labels"].numpy()) and np.array_equal(plan["attention_mask"], aux["attention_mask"].numpy())
+    assert plan["S"] == max_len and plan["lens"].tolist() == [13 + 16, 9 + 16, 30, 6]
+    assert abs(float(loss) - float(rl)) < 5e-3, (float(loss), float(rl))
+    m = aux["attention_mask"]
+    ref = rlog.detach()[m]
+    assert float((logits[m] - ref).abs().max() / ref.abs().max()) < 3e-2
+    for k in ("model.embed_tokens.weight", "model.mm_projector.2.weight", "model.layers.0.self_attn.q_proj.weight", "lm_head.weight"):
+        got, want = eng.G(k).float().cpu(), P[k].grad
+        assert float((got - want).norm() / want.norm()) < 5e-2, k
