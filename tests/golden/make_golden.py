@@ -383,5 +383,38 @@ if __name__ == "__main__":
                 grads_full=("model.image_newline", vp + "embeddings.patch_embedding.bias",
                             vp + "encoder.layers.0.self_attn.q_proj.bias", vp + "encoder.layers.1.mlp.fc1.bias",
                             vp + "embeddings.position_embedding.weight"))
+    if "edge" in which:
+        # splice edge cases (llava_arch.py:442-531): image placeholder first / last, two images in one sample, a text-only
+        # sample, ragged lengths, truncation at tokenizer_model_max_length through an image span -- inputs built exactly as in
+        # tests/test_e2e_gpu.py::test_edge_cases_against_oracle (torch generator seed 11)
+        geo = GEOMETRIES["toy"]
+        model = build_reference_model(mods, geo)
+        model.config.tokenizer_model_max_length = 30
+        g = torch.Generator().manual_seed(11)
+        T = 14
+        ids = torch.randint(3, 1000, (4, T), generator=g)
+        labels = ids.clone()
+        mask = torch.ones(4, T, dtype=torch.bool)
+        ids[0, 0] = -200
+        ids[1, 9] = -200; mask[1, 10:] = False
+        ids[2, 3] = -200; ids[2, 8] = -200
+        mask[3, 6:] = False
+        labels[ids == -200] = -100
+        labels[:, :2] = -100
+        ids[~mask] = 0; labels[~mask] = -100
+        images = [torch.randn(3, 56, 56, generator=g).to(torch.bfloat16).float() for _ in range(4)] + [torch.zeros(3, 56, 56)]
+        modalities = ["image"] * 4 + ["text"]
+        sizes = [[56, 56]] * 5
+        with torch.no_grad():
+            (_, _, attn, _, embeds, new_labels) = model.prepare_inputs_labels_for_multimodal(ids, None, mask, None, labels, images, modalities, sizes)
+        out = model(input_ids=ids, attention_mask=mask, labels=labels, images=images, image_sizes=sizes, modalities=modalities)
+        out.loss.backward()
+        gn = {canonical_name(k): (None if p.grad is None else float(p.grad.norm())) for k, p in model.named_parameters()}
+        np.savez_compressed(os.path.join(HERE, "toy_edge_e2e.npz"), input_ids=ids.numpy(), labels=labels.numpy(), attention_mask=mask.numpy(),
+                            splice_labels=new_labels.numpy(), splice_attention_mask=attn.numpy(), loss=out.loss.detach().numpy().astype(np.float32),
+                            logits=out.logits.detach().numpy().astype(np.float32)[:, :, ::5].copy(), **{f"image{i}": im.numpy() for i, im in enumerate(images)})
+        with open(os.path.join(HERE, "toy_edge_e2e_gradnorms.json"), "w") as f:
+            json.dump({"geometry": "toy", "max_len": 30, "grad_norms": gn, "loss": float(out.loss)}, f, indent=1)
+        print("toy_edge_e2e loss", float(out.loss), "embeds", tuple(embeds.shape))
     if "cfg1" in which:
         run_e2e(mods, "config1", [(48, 35, 40)], "config1_e2e")

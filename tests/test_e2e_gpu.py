@@ -527,6 +527,28 @@ def test_training_reduces_the_loss(golden_dir, name, golden, kw):
 
 
 @pytest.mark.parametrize("packed", [False, True])
+def test_edge_cases_against_reference_golden(golden_dir, packed):
+    """The same edge-case batch against the REFERENCE's own outputs (tests/golden/toy_edge_e2e.*, make_golden.py edge)."""
+    g, meta, _ = _golden(golden_dir, "toy_edge_e2e")
+    images = [torch.from_numpy(g[f"image{i}"]) for i in range(5)]
+    eng = _engine("toy", max_len=meta["max_len"], packed=packed)
+    loss = eng.forward(g["input_ids"], g["attention_mask"], g["labels"], images, want_logits=True)
+    logits = eng.last_logits.cpu()
+    plan = eng.ctx["plan"]
+    eng.backward()
+    torch.cuda.synchronize()
+    assert np.array_equal(plan["labels"], g["splice_labels"]) and np.array_equal(plan["attention_mask"], g["splice_attention_mask"])
+    assert abs(float(loss) - float(g["loss"])) < 5e-3
+    m = torch.from_numpy(g["splice_attention_mask"])
+    ref = torch.from_numpy(g["logits"])
+    assert float((logits[:, :, ::5][m] - ref[m]).abs().max() / ref[m].abs().max()) < 3e-2
+    for k, want in meta["grad_norms"].items():
+        if want is not None and k in eng.lm.offsets:
+            got = float(eng.G(k).float().norm())
+            assert abs(got - want) < 5e-2 * want + 1e-5, (k, got, want)
+
+
+@pytest.mark.parametrize("packed", [False, True])
 def test_edge_cases_against_oracle(packed):
     """Edge cases of the splice (llava_arch.py:442-531) through the HIP engine vs the CPU oracle: an image placeholder at the
     first and at the last position, two images in one sample, a text-only sample (consumes a dummy image, contributes no rows),

@@ -196,3 +196,26 @@ def test_e2e_config1(golden_dir):
     lg = logits.detach().numpy()
     assert _maxrel(lg[:, ::7, ::997], g["logits_slice"]) < 1e-4
     assert abs(np.abs(lg).max() - float(g["logits_absmax"].max())) < 1e-4
+
+
+def test_e2e_toy_edge_cases(golden_dir):
+    """Splice edge cases pinned against the reference (make_golden.py edge): image placeholder first / last, two images in one
+    sample, a text-only sample, ragged lengths, truncation at tokenizer_model_max_length through an image span."""
+    g = _load(golden_dir, "toy_edge_e2e.npz")
+    meta = json.load(open(os.path.join(golden_dir, "toy_edge_e2e_gradnorms.json")))
+    geo = GEOMETRIES["toy"]
+    P = O.make_params(geo, seed=0)
+    for k, v in P.items():
+        if "vision_tower" not in k:
+            v.requires_grad_(True)
+    images = [torch.from_numpy(g[f"image{i}"]) for i in range(5)]
+    loss, logits, aux = O.llava_forward(P, geo, torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"]),
+                                        torch.from_numpy(g["labels"]), images, cfg={"tokenizer_model_max_length": meta["max_len"]})
+    loss.backward()
+    assert np.array_equal(aux["labels"].numpy(), g["splice_labels"]) and np.array_equal(aux["attention_mask"].numpy(), g["splice_attention_mask"])
+    assert abs(float(loss) - float(g["loss"])) < 2e-5
+    m = g["splice_attention_mask"]
+    assert _maxrel(logits.detach().numpy()[:, :, ::5][m], g["logits"][m]) < 1e-4
+    for k, want in meta["grad_norms"].items():
+        if want is not None:
+            assert abs(float(P[k].grad.norm()) - want) <= 2e-4 * max(want, 1e-3), k
