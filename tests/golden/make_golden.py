@@ -416,5 +416,13 @@ if __name__ == "__main__":
         with open(os.path.join(HERE, "toy_edge_e2e_gradnorms.json"), "w") as f:
             json.dump({"geometry": "toy", "max_len": 30, "grad_norms": gn, "loss": float(out.loss)}, f, indent=1)
         print("toy_edge_e2e loss", float(out.loss), "embeds", tuple(embeds.shape))
+    if "edge2" in which:
+        # (a) 'spatial' merge (no unpad, no image_newline) with anyres tiles; (b) a batch of text-only samples (dummy images only)
+        pin = [[56, 112], [112, 56], [112, 112], [168, 56], [56, 168]]
+        sizes = [[112, 112], [150, 50]]
+        tiles = [1 + int(np.prod(mods["mm_utils"].get_anyres_image_grid_shape(sz, pin, 56))) for sz in sizes]
+        run_e2e(mods, "toy", [(14, 4, 6), (10, 2, 3)], "toy_spatial_e2e", merge_type="spatial", aspect="anyres", pinpoints=pin, tiles=tiles,
+                image_sizes=sizes, slices=True)
+        run_e2e(mods, "toy", [(11, None, 2), (7, None, 1)], "toy_textonly_e2e", slices=True)
     if "cfg1" in which:
         run_e2e(mods, "config1", [(48, 35, 40)], "config1_e2e")

@@ -141,6 +141,25 @@ def test_toy_qwen2_anyres_max_tower_tunable(golden_dir, packed):
     assert bool(torch.isfinite(eng.lm.flat.float()).all())
 
 
+def test_toy_spatial_merge_and_text_only_batch(golden_dir):
+    """'spatial' merge without unpad / newline, and a batch made of text-only samples (the projector receives zero gradient)."""
+    g, meta, images = _golden(golden_dir, "toy_spatial_e2e")
+    eng = _engine("toy", merge_type=meta["merge_type"], image_aspect_ratio=meta["aspect"], image_grid_pinpoints=meta["pinpoints"])
+    sizes = [tuple(s) for s in g["image_sizes"].tolist()]
+    loss, logits, plan = _run(eng, g, images, sizes)
+    _check(eng, g, meta, loss, logits, plan, full=False)
+    _check_slices(eng, g, logits, images)
+    g, meta, images = _golden(golden_dir, "toy_textonly_e2e")
+    eng = _engine("toy")
+    loss, logits, plan = _run(eng, g, images)
+    assert np.array_equal(plan["labels"], g["splice_labels"]) and abs(loss - float(g["loss"])) < 5e-3
+    _check_slices(eng, g, logits, images)
+    for k, want in meta["grad_norms"].items():
+        if k in eng.lm.offsets:
+            got = float(eng.G(k).float().norm())
+            assert abs(got - (want or 0.0)) < 5e-2 * (want or 0.0) + 1e-5, (k, got, want)
+
+
 def test_config1(golden_dir):
     g, meta, images = _golden(golden_dir, "config1_e2e")
     eng = _engine("config1")

@@ -219,3 +219,15 @@ def test_e2e_toy_edge_cases(golden_dir):
     for k, want in meta["grad_norms"].items():
         if want is not None:
             assert abs(float(P[k].grad.norm()) - want) <= 2e-4 * max(want, 1e-3), k
+
+
+def test_e2e_toy_spatial_and_text_only(golden_dir):
+    """'spatial' merge without unpad (llava_arch.py:404-406) and an all-text batch (dummy images only, :452-459)."""
+    g, meta, P, loss, logits, aux = _run_e2e(golden_dir, "toy_spatial_e2e")
+    _check_common(g, meta, P, loss, logits, aux)
+    _check_slices(g, P, logits, aux)
+    g, meta, P, loss, logits, aux = _run_e2e(golden_dir, "toy_textonly_e2e")
+    _check_common(g, meta, P, loss, logits, aux)
+    lg = logits.detach().numpy()
+    assert _maxrel(lg[:, ::7, ::997], g["logits_slice"]) < 1e-4
+    assert P["model.mm_projector.0.weight"].grad is None or float(P["model.mm_projector.0.weight"].grad.abs().max()) == 0.0
