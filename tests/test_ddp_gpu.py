@@ -21,16 +21,17 @@ from radvlm_amd.smoke import load_golden_batch
 rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=rank, world_size=world)
-g, images = load_golden_batch("toy_e2e")
+GEO, GOLD, KW = {geo!r}, {gold!r}, {kw!r}
+g, images = load_golden_batch(GOLD)
 # rank r trains on samples [r, 2] (rank-dependent batch)
 sel = [rank, 2]
 ids, am, lab = g["input_ids"][sel], g["attention_mask"][sel], g["labels"][sel]
 imgs = [images[i] for i in sel]
-solo = LlavaEngine(GEOMETRIES["toy"], device="cuda:0", init="portable", seed=0)
+solo = LlavaEngine(GEOMETRIES[GEO], device="cuda:0", init="portable", seed=0, **KW)
 solo.forward(ids, am, lab, imgs); solo.backward()
 torch.cuda.synchronize()
 mine = solo.grads.float().clone()
-eng = LlavaEngine(GEOMETRIES["toy"], device="cuda:0", init="portable", seed=0, process_group=dist.group.WORLD)
+eng = LlavaEngine(GEOMETRIES[GEO], device="cuda:0", init="portable", seed=0, process_group=dist.group.WORLD, **KW)
 assert eng.world == 2 and eng.sync is not None
 eng.forward(ids, am, lab, imgs); eng.backward(); eng.finish_grad_sync()
 torch.cuda.synchronize()
@@ -51,11 +52,12 @@ print("OK", rank, rel)
 """
 
 
-def test_engine_ddp_two_ranks_one_gpu(tmp_path):
+@pytest.mark.parametrize("geo,gold,kw", [("toy", "toy_e2e", {}), ("toy_qwen", "toy_qwen_e2e", {"train_vision_tower": True})])
+def test_engine_ddp_two_ranks_one_gpu(tmp_path, geo, gold, kw):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     script = tmp_path / "w.py"
-    script.write_text(WORKER.format(root=ROOT))
+    script.write_text(WORKER.format(root=ROOT, geo=geo, gold=gold, kw=kw))
     procs = []
     for r in range(2):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
