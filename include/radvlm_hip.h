@@ -156,6 +156,9 @@ int rv_swiglu_bwd(const void* dact, int64_t ld_dact, const void* gu, int64_t ld_
 /* Inverted dropout with a counter-based mask: y[i] = keep(seed, i) ? x[i] / (1 - p) : 0, keep = hash(seed, i) >= p.
  * The same (seed, p) regenerates the mask, so backward applies the same call to the gradient (lora_dropout). */
 int rv_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, void* stream);
+/* y += dropout(x) with the same mask as rv_dropout_bf16(p, seed): the adapter branch of a LoRA layer's input gradient,
+ * dx += dropout'(dt A), in one pass (peft LoraLayer: lora_dropout is applied to the layer input, so its adjoint masks dt A). */
+int rv_dropout_add_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, void* stream);
 /* torch.nn.GELU (erf) of the mm_projector (multimodal_projector/builder.py:44) and its derivative. */
 int rv_gelu_fwd(const void* x, void* y, int64_t n, void* stream);
 int rv_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);

@@ -360,6 +360,17 @@ __global__ void dropout_kernel(const bf16* x, bf16* y, long n8, unsigned thr, fl
     st8(y + i * 8, o);
 }
 
+__global__ void dropout_add_kernel(const bf16* x, bf16* y, long n8, unsigned thr, float scale, unsigned long long seed) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    float v[8], o[8];
+    ld8(x + i * 8, v);
+    ld8(y + i * 8, o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] += hash32(seed, (unsigned long long)(i * 8 + j)) >= thr ? v[j] * scale : 0.f;
+    st8(y + i * 8, o);
+}
+
 __global__ void gelu_fwd_kernel(const bf16* x, bf16* y, long n8) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n8) return;
@@ -777,6 +788,12 @@ extern "C" int rv_dropout_bf16(const void* x, void* y, int64_t n, float p, uint6
     if (!x || !y || n <= 0 || (n & 7) || p < 0.f || p >= 1.f) return RV_ERR_ARG;
     const unsigned thr = (unsigned)((double)p * 4294967296.0);
     hipLaunchKernelGGL(dropout_kernel, dim3(nblocks(n / 8, 256)), dim3(256), 0, ST, (const bf16*)x, (bf16*)y, (long)(n / 8), thr, 1.f / (1.f - p), (unsigned long long)seed);
+    return rv_check_launch();
+}
+extern "C" int rv_dropout_add_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, void* stream) {
+    if (!x || !y || n <= 0 || (n & 7) || p < 0.f || p >= 1.f) return RV_ERR_ARG;
+    const unsigned thr = (unsigned)((double)p * 4294967296.0);
+    hipLaunchKernelGGL(dropout_add_kernel, dim3(nblocks(n / 8, 256)), dim3(256), 0, ST, (const bf16*)x, (bf16*)y, (long)(n / 8), thr, 1.f / (1.f - p), (unsigned long long)seed);
     return rv_check_launch();
 }
 extern "C" int rv_gelu_fwd(const void* x, void* y, int64_t n, void* stream) {

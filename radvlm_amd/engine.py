@@ -551,9 +551,7 @@ class LlavaEngine:
                 seed = self._lora_seed(i, lname)
                 ops.gemm(dts, ops.dropout(x, self.lora_p, seed), ta=True, tb=True, out=gA, residual=gA if acc else None, workspace=ws)
                 ops.gemm(dyj, w[c0:c1], tb=True, out=dx, residual=None if first else dx)
-                tmp = ops.dropout(ops.gemm(dts, A, tb=True), self.lora_p, seed)
-                from . import lib
-                lib.call("rv_add_bf16", dx, tmp, dx, dx.numel())
+                ops.dropout_add(ops.gemm(dts, A, tb=True), dx, self.lora_p, seed)   # dx += dropout'(dts A), one pass
             else:
                 ops.gemm(dts, x, ta=True, tb=True, out=gA, residual=gA if acc else None, workspace=ws)
                 ops.gemm(dyj, w[c0:c1], tb=True, out=dx, residual=None if first else dx, a2=dts, b2=A)

@@ -299,6 +299,13 @@ def dropout(x, p, seed, y=None):
     return y
 
 
+def dropout_add(x, y, p, seed):
+    """y += dropout(x) (same regenerable mask as dropout(x, p, seed)), one pass."""
+    assert x.is_contiguous() and y.is_contiguous() and x.shape == y.shape
+    lib.call("rv_dropout_add_bf16", x, y, x.numel(), float(p), int(seed))
+    return y
+
+
 def gelu_fwd(x, y=None):
     assert x.is_contiguous()
     y = torch.empty_like(x) if y is None else y

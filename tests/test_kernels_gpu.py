@@ -551,3 +551,12 @@ def test_legacy_entry_points_match_the_extended_ones(ops):
     lib.call("rv_attn_bwd", q, q.stride(0), k, k.stride(0), v, v.stride(0), out, out.stride(0), dout, dout.stride(0), qT, kT, doT, lse, delta,
              g[0], d, g[1], d, g[2], d, None, B, H, S, s_pad, hd, 1, hd ** -0.5, lib.zeros16(q.device))
     assert torch.equal(g[0], dq) and torch.equal(g[1], dk) and torch.equal(g[2], dv)
+
+
+def test_dropout_add_matches_dropout_then_add(ops):
+    x, y = rnd(160, (64, 520), 1.0).cuda(), rnd(161, (64, 520), 1.0).cuda()
+    want = (y.float() + ops.dropout(x, 0.25, 77).float()).to(torch.bfloat16)
+    got = ops.dropout_add(x, y.clone(), 0.25, 77)
+    assert relerr(got.cpu().float(), want.cpu().float()) < TOL
+    kept = ops.dropout(x, 0.25, 77) != 0
+    assert torch.equal(got[~kept], y[~kept])          # dropped positions are untouched
