@@ -5,7 +5,7 @@
  * (file:line under /root/reference/finetuning/llava, or HF: = transformers as pinned by the reference) whose
  * arithmetic it replaces.  Conventions for every function:
  *   - plain device pointers + sizes, no torch types; bf16 = raw uint16 storage; strides (ld*) in ELEMENTS;
- *   - asynchronous on `stream` (a hipStream_t), no allocation, no host sync, no global state;
+ *   - asynchronous on `stream` (a hipStream_t), no allocation, no host sync, no global state (except the rv_gemm_select_kernel measurement hook);
  *   - `zeros16` is any 16-byte-aligned device buffer of >= 16 zero bytes (source for out-of-range tile chunks);
  *   - returns 0 (RV_OK) or a negative error code (RV_ERR_*), which the Python binding raises as an exception.
  */
@@ -55,7 +55,8 @@ int rv_gemm_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void
                     const void* residual, int64_t ldr, int M, int N, int K, int trans_a, int trans_b, float alpha, int act,
                     int out_f32, int res_f32, const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int K2,
                     void* workspace, int64_t workspace_bytes, const void* zeros16, void* stream);
-/* Tuning hook: 0 = automatic tile selection (default), 1 = 128x128 tile kernel, 2 = 256x256 tile kernel. */
+/* Measurement hook, the ONE piece of process-global state in the library (A/B tools and tests only; the product path never
+ * calls it): 0 = automatic tile selection (default), 1 = 128x128 tile kernel, 2 = 256x256 tile kernel, 20 / 21 = tail split off / on. */
 int rv_gemm_select_kernel(int which);
 
 /* Batched strided transpose of bf16 matrices: out[bz][c][r] = in[bz][r][c], r < R, c < C; columns r in [R, R_pad)
