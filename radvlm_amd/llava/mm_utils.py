@@ -118,6 +118,47 @@ def process_anyres_image(image, processor, grid_pinpoints):
     return torch.stack([processor.preprocess(t, return_tensors="pt")["pixel_values"][0] for t in tiles], 0)
 
 
+def _center_crop_to_short_edge(image, edge):
+    """Resize so the SHORT side equals `edge` (long side by the aspect ratio, truncated), then centre-crop an edge x edge
+    square (mm_utils.py:12-30; the reference's Image.ANTIALIAS filter is Pillow's LANCZOS, its name since Pillow 10)."""
+    ar = float(image.width) / float(image.height)
+    nw, nh = (int(edge * ar), edge) if ar > 1 else (edge, int(edge / ar))
+    im = image.resize((nw, nh), Image.LANCZOS)
+    left, top = (nw - edge) / 2, (nh - edge) / 2
+    return im.crop((left, top, left + edge, top + edge))
+
+
+def extract_patches(image, patch_size, overlap_ratio):
+    """Row-major grid of patch_size squares with the given overlap, centred in the image (mm_utils.py:62-85)."""
+    assert patch_size > 0 and 0 <= overlap_ratio < 1
+    W, H = image.size
+    stride = int(patch_size * (1 - overlap_ratio))
+    ny, nx = (H - patch_size) // stride + 1, (W - patch_size) // stride + 1
+    y0, x0 = (H - (ny - 1) * stride - patch_size) // 2, (W - (nx - 1) * stride - patch_size) // 2
+    return [image.crop((x, y, x + patch_size, y + patch_size))
+            for y in range(y0, y0 + ny * stride, stride) for x in range(x0, x0 + nx * stride, stride)]
+
+
+def process_highres_image_crop_split(image, data_args, processor=None):
+    """image_aspect_ratio='crop_split' (mm_utils.py:88-97): centre crop at image_crop_resolution, split into
+    image_split_resolution tiles, preprocess each -> [tiles, 3, s, s] (no base tile)."""
+    processor = processor or data_args.image_processor
+    crop = _center_crop_to_short_edge(image, data_args.image_crop_resolution)
+    tiles = extract_patches(crop, data_args.image_split_resolution, 0)
+    return torch.stack([processor.preprocess(t, return_tensors="pt")["pixel_values"][0] for t in tiles], 0)
+
+
+def process_highres_image(image, processor, grid_pinpoints):
+    """image_aspect_ratio='highres' (mm_utils.py:100-118): the largest size of the comma-separated `grid_pinpoints` is always
+    selected (the reference's FIXME), the image is padded to a square with the processor mean, resized to that size and cut
+    into shortest_edge tiles; the globally resized image comes first -> [1 + tiles, 3, s, s]."""
+    select = max(int(x) for x in grid_pinpoints.split(","))
+    edge = processor.size["shortest_edge"]
+    padded = expand2square(image, tuple(int(x * 255) for x in processor.image_mean)).resize((select, select))
+    tiles = [image.resize((edge, edge))] + extract_patches(padded, edge, 0)
+    return torch.stack([processor.preprocess(t, return_tensors="pt")["pixel_values"][0] for t in tiles], 0)
+
+
 def expand2square(pil_img, background_color):
     w, h = pil_img.size
     if w == h:
@@ -135,8 +176,10 @@ def process_images(images, image_processor, model_cfg):
     elif aspect == "pad":
         bg = tuple(int(x * 255) for x in image_processor.image_mean)
         out = [image_processor.preprocess(expand2square(im, bg), return_tensors="pt")["pixel_values"][0] for im in images]
-    elif aspect in ("highres", "crop_split"):
-        raise NotImplementedError(f"image_aspect_ratio={aspect} is outside the hot path (SURVEY.md section 8)")
+    elif aspect == "highres":
+        out = [process_highres_image(im, image_processor, model_cfg.image_grid_pinpoints) for im in images]
+    elif aspect == "crop_split":
+        out = [process_highres_image_crop_split(im, model_cfg, image_processor) for im in images]
     else:
         return image_processor.preprocess(images, return_tensors="pt")["pixel_values"]
     if all(x.shape == out[0].shape for x in out):

@@ -25,7 +25,8 @@ from torch.utils.data import Dataset
 
 from .. import conversation as conversation_lib
 from ..constants import DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN, DEFAULT_IMAGE_TOKEN, IGNORE_INDEX, IMAGE_TOKEN_INDEX
-from ..mm_utils import ClipImageProcessor, expand2square, process_anyres_image, tokenizer_image_token
+from ..mm_utils import (ClipImageProcessor, expand2square, process_anyres_image, process_highres_image,
+                        process_highres_image_crop_split, tokenizer_image_token)
 from .llava_trainer import LLaVATrainer
 
 
@@ -386,8 +387,10 @@ class LazySupervisedDataset(Dataset):
             t = process_anyres_image(image, proc, self.data_args.image_grid_pinpoints)
         elif aspect == "pad":
             t = proc.preprocess(expand2square(image, tuple(int(x * 255) for x in proc.image_mean)), return_tensors="pt")["pixel_values"][0]
-        elif aspect in ("highres", "crop_split"):
-            raise NotImplementedError(aspect)
+        elif aspect == "highres":
+            t = process_highres_image(image, proc, self.data_args.image_grid_pinpoints)
+        elif aspect == "crop_split":
+            t = process_highres_image_crop_split(image, self.data_args)
         else:
             t = proc.preprocess(image, return_tensors="pt")["pixel_values"][0]
         return t, size, "image"

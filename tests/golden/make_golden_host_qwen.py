@@ -42,10 +42,39 @@ def main():
         arrs[f"siglip_pre{k}"] = px.numpy()[:, ::8, ::8].copy()
         arrs[f"siglip_pre{k}_mean"] = px.numpy().reshape(3, -1).mean(1)
         out.setdefault("siglip_shapes", []).append(list(px.shape))
+    # highres / crop_split image modes (mm_utils.py:12-118) through the reference functions; Pillow >= 10 renamed the
+    # ANTIALIAS filter the reference names to LANCZOS (same filter): alias it for the run
+    from PIL import Image as _I
+    if not hasattr(_I, "ANTIALIAS"):
+        _I.ANTIALIAS = _I.LANCZOS
+    mmu = importlib.import_module("llava.mm_utils")
+    from types import SimpleNamespace
+    from transformers import CLIPImageProcessor
+    hf = CLIPImageProcessor(size={"shortest_edge": 112}, crop_size={"height": 112, "width": 112})
+
+    class Adapter:
+        size = {"shortest_edge": 112}
+        crop_size = {"height": 112, "width": 112}
+        image_mean = hf.image_mean
+
+        def preprocess(self, image, return_tensors="pt"):
+            return hf.preprocess(image, return_tensors=return_tensors)
+
+    out["highres_shapes"], out["crop_split_shapes"] = [], []
+    for k, (w, h) in enumerate([(500, 400), (300, 900)]):
+        t = mmu.process_highres_image(img(k, w, h), Adapter(), "224,336,448")
+        arrs[f"highres{k}"] = t.numpy()[:, :, ::8, ::8].copy()
+        arrs[f"highres{k}_mean"] = t.numpy().reshape(t.shape[0], -1).mean(1)
+        out["highres_shapes"].append(list(t.shape))
+        da = SimpleNamespace(image_crop_resolution=448, image_split_resolution=112, image_processor=Adapter())
+        t = mmu.process_highres_image_crop_split(img(k, w, h), da)
+        arrs[f"crop_split{k}"] = t.numpy()[:, :, ::8, ::8].copy()
+        arrs[f"crop_split{k}_mean"] = t.numpy().reshape(t.shape[0], -1).mean(1)
+        out["crop_split_shapes"].append(list(t.shape))
     with open(os.path.join(HERE, "host_golden_qwen.json"), "w") as f:
         json.dump(out, f)
     np.savez_compressed(os.path.join(HERE, "host_images_qwen.npz"), **arrs)
-    print("written", [len(q["input_ids"]) for q in out["qwen"]], out["siglip_shapes"])
+    print("written", [len(q["input_ids"]) for q in out["qwen"]], out["siglip_shapes"], out["highres_shapes"], out["crop_split_shapes"])
 
 
 if __name__ == "__main__":

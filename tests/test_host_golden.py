@@ -242,3 +242,22 @@ def test_preprocess_qwen_and_siglip_processor(golden_dir):
         assert list(px.shape) == H["siglip_shapes"][i]
         assert np.abs(px.numpy()[:, ::8, ::8] - A[f"siglip_pre{i}"]).max() < 1e-5
         assert np.abs(px.numpy().reshape(3, -1).mean(1) - A[f"siglip_pre{i}_mean"]).max() < 1e-5
+
+
+def test_highres_and_crop_split_image_modes(golden_dir):
+    """image_aspect_ratio = 'highres' / 'crop_split' (mm_utils.py:12-118) against the reference's outputs."""
+    from types import SimpleNamespace
+    from radvlm_amd.llava.mm_utils import ClipImageProcessor, process_highres_image, process_highres_image_crop_split
+    H = json.load(open(os.path.join(golden_dir, "host_golden_qwen.json")))
+    A = np.load(os.path.join(golden_dir, "host_images_qwen.npz"))
+    proc = ClipImageProcessor(112)
+    for i, (w, h) in enumerate([(500, 400), (300, 900)]):
+        t = process_highres_image(img(i, w, h), proc, "224,336,448")
+        assert list(t.shape) == H["highres_shapes"][i]
+        assert np.abs(t.numpy()[:, :, ::8, ::8] - A[f"highres{i}"]).max() < 2e-2        # PIL-vs-HF bicubic rounding, as for the CLIP processor
+        assert np.abs(t.numpy().reshape(t.shape[0], -1).mean(1) - A[f"highres{i}_mean"]).max() < 2e-3
+        da = SimpleNamespace(image_crop_resolution=448, image_split_resolution=112, image_processor=proc)
+        t = process_highres_image_crop_split(img(i, w, h), da)
+        assert list(t.shape) == H["crop_split_shapes"][i]
+        assert np.abs(t.numpy()[:, :, ::8, ::8] - A[f"crop_split{i}"]).max() < 2e-2
+        assert np.abs(t.numpy().reshape(t.shape[0], -1).mean(1) - A[f"crop_split{i}_mean"]).max() < 2e-3
