@@ -189,6 +189,14 @@ int rv_weighted_segment_sum_rows(const void* src, int64_t ld_src, const int32_t*
                                  const float* w, const int32_t* out_row, int nseg, void* out, int64_t ld_out, int d,
                                  void* stream);
 
+/* 'maxpool2x2' patch merge (nn.functional.max_pool2d(grid, 2), llava_arch.py:375-379): out[out_row[s]] = elementwise max of the
+ * four rows src[idx4[4s..4s+3]] (window scan order; `which` keeps the winning slot per element); backward routes the gradient
+ * of every pooled row to the winning source element and zero to the other three (windows do not overlap: no atomics). */
+int rv_max4_rows_fwd(const void* src, int64_t ld_src, const int32_t* idx4, const int32_t* out_row, int n, void* out, int64_t ld_out,
+                     uint8_t* which, int d, void* stream);
+int rv_max4_rows_bwd(const void* dout, int64_t ld_dout, const int32_t* idx4, const int32_t* dout_row, int n, const uint8_t* which,
+                     void* dsrc, int64_t ld_dsrc, int d, void* stream);
+
 /* ---- CLIP embeddings -----------------------------------------------------------------------------------------------
  * HF:modeling_clip.py:202-218: patches of pix [n,3,H,W] (bf16) -> rows [n*gh*gw, Kp], k = c*p*p + i*p + j (zero
  * padded to Kp); then out[n, 0] = cls + pos[0], out[n, 1+i] = patch_out[n, i] + pos[1+i]. */

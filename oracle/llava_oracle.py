@@ -338,7 +338,10 @@ def merge_image_features(feats_per_sample, cfg, P, image_sizes, side):
             base, rest = f[0], f[1:]
             gw, gh = get_anyres_image_grid_shape(image_sizes[idx], cfg["image_grid_pinpoints"], cfg["tower_image_size"])
             rest = rest.view(gh, gw, side, side, -1)
-            if "unpad" in mt:
+            if "maxpool2x2" in mt:   # llava_arch.py:375-379
+                rest = rest.permute(4, 0, 2, 1, 3).contiguous().flatten(1, 2).flatten(2, 3)
+                rest = F.max_pool2d(rest, 2).flatten(1, 2).transpose(0, 1)
+            elif "unpad" in mt:
                 rest = rest.permute(4, 0, 2, 1, 3).contiguous().flatten(1, 2).flatten(2, 3)
                 rest = unpad_image(rest, image_sizes[idx])
                 mx = re.match(r"anyres_max_(\d+)", cfg.get("image_aspect_ratio", ""))

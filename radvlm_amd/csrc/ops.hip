@@ -535,6 +535,46 @@ __global__ void weighted_segment_sum_rows_kernel(const bf16* src, long ld_src, c
     }
 }
 
+// out[out_row[s]] = elementwise max of the four rows src[idx4[s][0..3]]; which[s][e] = index (0..3) of the first maximum
+// (nn.functional.max_pool2d's window scan order), kept for the backward pass.
+__global__ void max4_rows_fwd_kernel(const bf16* src, long ld_src, const int* idx4, const int* out_row, bf16* out, long ld_out,
+                                     unsigned char* which, int d) {
+    const int s = blockIdx.x;
+    bf16* o = out + (long)out_row[s] * ld_out;
+    for (int e = threadIdx.x * 8; e < d; e += blockDim.x * 8) {
+        float best[8];
+        int arg[8];
+        ld8(src + (long)idx4[s * 4] * ld_src + e, best);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) arg[i] = 0;
+        for (int j = 1; j < 4; ++j) {
+            float v[8];
+            ld8(src + (long)idx4[s * 4 + j] * ld_src + e, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) if (v[i] > best[i] || v[i] != v[i]) { best[i] = v[i]; arg[i] = j; }
+        }
+        st8(o + e, best);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) which[(long)s * d + e + i] = (unsigned char)arg[i];
+    }
+}
+// dsrc[idx4[s][j]][e] = which[s][e] == j ? dout[dout_row[s]][e] : 0   (every source row belongs to exactly one window)
+__global__ void max4_rows_bwd_kernel(const bf16* dout, long ld_dout, const int* idx4, const int* dout_row, const unsigned char* which,
+                                     bf16* dsrc, long ld_dsrc, int d) {
+    const int s = blockIdx.x;
+    const bf16* g = dout + (long)dout_row[s] * ld_dout;
+    for (int e = threadIdx.x * 8; e < d; e += blockDim.x * 8) {
+        float gv[8];
+        ld8(g + e, gv);
+        for (int j = 0; j < 4; ++j) {
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = which[(long)s * d + e + i] == j ? gv[i] : 0.f;
+            st8(dsrc + (long)idx4[s * 4 + j] * ld_dsrc + e, o);
+        }
+    }
+}
+
 __global__ void add_pos_rows_kernel(bf16* x, const bf16* pos, long total, long per_image) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -835,6 +875,18 @@ extern "C" int rv_weighted_segment_sum_rows(const void* src, int64_t ld_src, con
     if ((((uintptr_t)src) | ((uintptr_t)out)) & 15) return RV_ERR_ARG;
     hipLaunchKernelGGL(weighted_segment_sum_rows_kernel, dim3(nseg), dim3(256), 0, ST, (const bf16*)src, (long)ld_src, seg_off, pos, w,
                        out_row, (bf16*)out, (long)ld_out, d);
+    return rv_check_launch();
+}
+extern "C" int rv_max4_rows_fwd(const void* src, int64_t ld_src, const int32_t* idx4, const int32_t* out_row, int n, void* out, int64_t ld_out,
+                                uint8_t* which, int d, void* stream) {
+    if (!src || !idx4 || !out_row || !out || !which || n <= 0 || d <= 0 || (d & 7) || (ld_src & 7) || (ld_out & 7)) return RV_ERR_ARG;
+    hipLaunchKernelGGL(max4_rows_fwd_kernel, dim3(n), dim3(256), 0, ST, (const bf16*)src, (long)ld_src, idx4, out_row, (bf16*)out, (long)ld_out, which, d);
+    return rv_check_launch();
+}
+extern "C" int rv_max4_rows_bwd(const void* dout, int64_t ld_dout, const int32_t* idx4, const int32_t* dout_row, int n, const uint8_t* which,
+                                void* dsrc, int64_t ld_dsrc, int d, void* stream) {
+    if (!dout || !idx4 || !dout_row || !which || !dsrc || n <= 0 || d <= 0 || (d & 7) || (ld_dout & 7) || (ld_dsrc & 7)) return RV_ERR_ARG;
+    hipLaunchKernelGGL(max4_rows_bwd_kernel, dim3(n), dim3(256), 0, ST, (const bf16*)dout, (long)ld_dout, idx4, dout_row, which, (bf16*)dsrc, (long)ld_dsrc, d);
     return rv_check_launch();
 }
 extern "C" int rv_add_pos_rows(void* x, const void* pos, int n, int P, int d, void* stream) {

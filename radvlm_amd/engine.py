@@ -334,7 +334,8 @@ class LlavaEngine:
         down-sampling (llava_arch.py:381-392; a 4-tap weighted gather of projector rows), then image_newline."""
         n = pixels.shape[0]
         rs = (plan or {}).get("resample")
-        n_extra = plan["n_extra_rows"] if rs else 0
+        mp = (plan or {}).get("maxpool")
+        n_extra = plan["n_extra_rows"] if (rs or mp) else 0
         d = self.l["d"]
         hid = self.vision_forward(pixels, save=save if (self.train_tower and save is not None) else None)
         if self.has_cls:
@@ -350,6 +351,10 @@ class LlavaEngine:
         if rs:
             t = lambda k: torch.from_numpy(rs[k]).to(self.device)
             ops.weighted_segment_sum_rows(table, t("fwd_off"), t("fwd_pos"), t("fwd_w"), t("fwd_out"), table)
+        if mp:
+            which = ops.max4_rows_fwd(table, torch.from_numpy(mp["idx4"]).to(self.device), torch.from_numpy(mp["out"]).to(self.device), table)
+            if save is not None:
+                save["pool_which"] = which
         if self.with_newline:
             table[n * self.P + n_extra].copy_(self.W("model.image_newline"))
         else:
@@ -378,15 +383,21 @@ class LlavaEngine:
         plan["n_feat_rows"] = n_proj + n_extra
         plan["n_proj_rows"] = n_proj
         plan["n_extra_rows"] = n_extra
-        if n_extra:
-            src = np.concatenate(extra["src"]).reshape(-1)            # [4 * n_extra] projector rows
+        if extra.get("pool_src"):   # maxpool2x2: created rows = elementwise max of four projector rows
+            win = np.concatenate(extra["pool_src"]).astype(np.int32)
+            assert (plan["feat_pos"][np.unique(win)] < 0).all()
+            plan["maxpool"] = dict(idx4=win.reshape(-1), out=np.concatenate(extra["pool_out"]).astype(np.int32))
+        if extra["src"]:
+            src = np.concatenate(extra["src"]).reshape(-1)            # [4 * n_resampled] projector rows
             w = np.concatenate(extra["w"]).reshape(-1).astype(np.float32)
             assert (plan["feat_pos"][np.unique(src)] < 0).all()       # a down-sampled grid's sources are never spliced directly
             order = np.argsort(src, kind="stable")
             usrc, starts = np.unique(src[order], return_index=True)
+            n_rs = src.shape[0] // 4
+            assert n_rs == n_extra or not extra.get("pool_src"), "anyres_max resampling and maxpool2x2 are mutually exclusive merges"
             plan["resample"] = dict(
-                fwd_off=np.arange(0, 4 * n_extra + 1, 4, dtype=np.int32), fwd_pos=src.astype(np.int32), fwd_w=w,
-                fwd_out=(n_proj + np.arange(n_extra)).astype(np.int32),
+                fwd_off=np.arange(0, 4 * n_rs + 1, 4, dtype=np.int32), fwd_pos=src.astype(np.int32), fwd_w=w,
+                fwd_out=(n_proj + np.arange(n_rs)).astype(np.int32),
                 # adjoint: for every source row, the (created row, weight) pairs it feeds
                 adj_off=np.concatenate([starts, [src.shape[0]]]).astype(np.int32),
                 adj_pos=(n_proj + order // 4).astype(np.int32), adj_w=w[order], adj_out=usrc.astype(np.int32))
@@ -612,6 +623,10 @@ class LlavaEngine:
         fpos = torch.from_numpy(plan["feat_pos"]).to(dev)
         dfeat = ops.gather_rows(fpos, d, dx)
         rs = plan.get("resample")
+        mp = plan.get("maxpool")
+        if mp:   # adjoint of the 2x2 max pooling: each pooled row's gradient goes to the winning source element
+            ops.max4_rows_bwd(dfeat, torch.from_numpy(mp["idx4"]).to(dev), torch.from_numpy(mp["out"]).to(dev), c["pool_which"], dfeat)
+            dfeat = dfeat[:plan["n_proj_rows"]]
         if rs:   # adjoint of the bilinear down-sampling: gradients of the created rows flow to their 4 source rows
             t = lambda k: torch.from_numpy(rs[k]).to(dev)
             ops.weighted_segment_sum_rows(dfeat, t("adj_off"), t("adj_pos"), t("adj_w"), t("adj_out"), dfeat)

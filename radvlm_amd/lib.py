@@ -55,6 +55,8 @@ _SIGS = {
     "rv_gelu_tanh_bwd": [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p],
     "rv_weighted_segment_sum_rows": [_c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i32, _c_void_p, _i64, _i32,
                                      _c_void_p],
+    "rv_max4_rows_fwd": [_c_void_p, _i64, _c_void_p, _c_void_p, _i32, _c_void_p, _i64, _c_void_p, _i32, _c_void_p],
+    "rv_max4_rows_bwd": [_c_void_p, _i64, _c_void_p, _c_void_p, _i32, _c_void_p, _c_void_p, _i64, _i32, _c_void_p],
     "rv_add_pos_rows": [_c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p],
     "rv_swiglu_fwd": [_c_void_p, _i64, _c_void_p, _i64, _i32, _i32, _c_void_p],
     "rv_swiglu_bwd": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _i32, _c_void_p],

@@ -359,6 +359,19 @@ def weighted_segment_sum_rows(src, seg_off, pos, w, out_row, out):
     return out
 
 
+def max4_rows_fwd(src, idx4, out_row, out):
+    """out[out_row[s]] = max over the four rows src[idx4[s]]; returns the per-element winning slot (uint8 [n, d])."""
+    n, d = out_row.numel(), src.shape[1]
+    which = torch.empty(n, d, dtype=torch.uint8, device=src.device)
+    lib.call("rv_max4_rows_fwd", src, src.stride(0), idx4, out_row, n, out, out.stride(0), which, d)
+    return which
+
+
+def max4_rows_bwd(dout, idx4, dout_row, which, dsrc):
+    lib.call("rv_max4_rows_bwd", dout, dout.stride(0), idx4, dout_row, dout_row.numel(), which, dsrc, dsrc.stride(0), dout.shape[1])
+    return dsrc
+
+
 def add_pos_rows(x, pos, n, P):
     """x [n*P, d] += pos [P, d] broadcast over images, in place."""
     assert x.is_contiguous() and pos.is_contiguous() and x.shape[0] == n * P and pos.shape[0] == P

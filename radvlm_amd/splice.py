@@ -98,7 +98,18 @@ def merged_feature_rows(row0, n_tiles, side, merge_type="flat", aspect="square",
             gw, gh = 2, 2
         rest = rest.reshape(gh, gw, side, side)
         if "maxpool2x2" in merge_type:
-            raise NotImplementedError("maxpool2x2 merge (not used by any shipped recipe)")
+            # llava_arch.py:375-379: 2x2 max pooling (stride 2, floor) of the tile grid; no image_newline.  Every pooled token is
+            # a NEW table row whose four source rows are recorded in extra["pool_src"] (the device takes the elementwise max).
+            if extra is None:
+                raise ValueError("maxpool2x2 merge needs the `extra` collector")
+            grid = rest.transpose(0, 2, 1, 3).reshape(gh * side, gw * side)
+            oh, ow = grid.shape[0] // 2, grid.shape[1] // 2
+            win = grid[:2 * oh, :2 * ow].reshape(oh, 2, ow, 2).transpose(0, 2, 1, 3).reshape(oh * ow, 4)   # (dy, dx) scan order
+            extra.setdefault("pool_src", []).append(win)
+            pooled = extra["next"] + np.arange(oh * ow, dtype=np.int64)
+            extra.setdefault("pool_out", []).append(pooled)
+            extra["next"] += oh * ow
+            return pooled if "nobase" in merge_type else np.concatenate([base, pooled])
         if "unpad" in merge_type:
             grid = rest.transpose(0, 2, 1, 3).reshape(gh * side, gw * side)
             grid = unpad_index(grid, image_size)

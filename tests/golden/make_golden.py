@@ -424,5 +424,12 @@ if __name__ == "__main__":
         run_e2e(mods, "toy", [(14, 4, 6), (10, 2, 3)], "toy_spatial_e2e", merge_type="spatial", aspect="anyres", pinpoints=pin, tiles=tiles,
                 image_sizes=sizes, slices=True)
         run_e2e(mods, "toy", [(11, None, 2), (7, None, 1)], "toy_textonly_e2e", slices=True)
+    if "pool" in which:
+        # 'spatial_maxpool2x2' merge (llava_arch.py:375-379) over anyres tiles: 2x2 grid -> 8x8 tokens pooled to 4x4; 3x1 grid -> 4x12 to 2x6
+        pin = [[56, 112], [112, 56], [112, 112], [168, 56], [56, 168]]
+        sizes = [[112, 112], [150, 50]]
+        tiles = [1 + int(np.prod(mods["mm_utils"].get_anyres_image_grid_shape(sz, pin, 56))) for sz in sizes]
+        run_e2e(mods, "toy", [(14, 4, 6), (10, 2, 3)], "toy_maxpool_e2e", merge_type="spatial_maxpool2x2", aspect="anyres", pinpoints=pin,
+                tiles=tiles, image_sizes=sizes, slices=True, grads_full=("model.mm_projector.2.weight",))
     if "cfg1" in which:
         run_e2e(mods, "config1", [(48, 35, 40)], "config1_e2e")

@@ -41,7 +41,7 @@ def _run(eng, g, images, sizes=None):
     return float(loss), logits, plan
 
 
-def _check(eng, g, meta, loss, logits, plan, full=True, loss_tol=5e-3):
+def _check(eng, g, meta, loss, logits, plan, full=True, loss_tol=5e-3, grad_rel=5e-2):
     assert np.array_equal(plan["labels"], g["splice_labels"])
     assert np.array_equal(plan["attention_mask"], g["splice_attention_mask"])
     assert abs(loss - float(g["loss"])) < loss_tol, (loss, float(g["loss"]))
@@ -67,7 +67,7 @@ def _check(eng, g, meta, loss, logits, plan, full=True, loss_tol=5e-3):
             ref = torch.from_numpy(g[k])
             got = eng.G(k[6:]).float().cpu()
             rel = float((got - ref).norm() / ref.norm())
-            assert rel < 5e-2, (k, rel)
+            assert rel < grad_rel, (k, rel)
     return worst
 
 
@@ -158,6 +158,22 @@ def test_toy_spatial_merge_and_text_only_batch(golden_dir):
         if k in eng.lm.offsets:
             got = float(eng.G(k).float().norm())
             assert abs(got - (want or 0.0)) < 5e-2 * (want or 0.0) + 1e-5, (k, got, want)
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_toy_maxpool2x2_merge(golden_dir, packed):
+    """'spatial_maxpool2x2': pooled tokens are new table rows (elementwise max of four projector rows, rv_max4_rows_fwd); the
+    backward routes each pooled gradient to the winning source element."""
+    g, meta, images = _golden(golden_dir, "toy_maxpool_e2e")
+    eng = _engine("toy", merge_type=meta["merge_type"], image_aspect_ratio=meta["aspect"], image_grid_pinpoints=meta["pinpoints"], packed=packed)
+    sizes = [tuple(s) for s in g["image_sizes"].tolist()]
+    loss, logits, plan = _run(eng, g, images, sizes)
+    assert plan["n_extra_rows"] == 16 + 12 and "maxpool" in plan
+    # stored-gradient tolerance 1e-1 here: where two candidates of a 2x2 window differ by less than a bf16 ulp the bf16 forward
+    # crowns a different winner than the fp32 reference and the whole gradient of that element moves to another source row
+    # (measured 6.3e-2 on the projector weight; norms, loss and logits stay within the usual gates)
+    _check(eng, g, meta, loss, logits, plan, full=False, grad_rel=1e-1)
+    _check_slices(eng, g, logits, images)
 
 
 def test_config1(golden_dir):

@@ -231,3 +231,10 @@ def test_e2e_toy_spatial_and_text_only(golden_dir):
     lg = logits.detach().numpy()
     assert _maxrel(lg[:, ::7, ::997], g["logits_slice"]) < 1e-4
     assert P["model.mm_projector.0.weight"].grad is None or float(P["model.mm_projector.0.weight"].grad.abs().max()) == 0.0
+
+
+def test_e2e_toy_maxpool2x2(golden_dir):
+    """'spatial_maxpool2x2' merge (llava_arch.py:375-379) over anyres tiles."""
+    g, meta, P, loss, logits, aux = _run_e2e(golden_dir, "toy_maxpool_e2e")
+    _check_common(g, meta, P, loss, logits, aux)
+    _check_slices(g, P, logits, aux)
