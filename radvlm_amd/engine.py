@@ -67,7 +67,7 @@ class LlavaEngine:
         if self.lora:
             # LoRA (BASELINE config 5): the language model is a frozen bf16 store; only adapters + projector are
             # trainable, so gradients / AdamW state / the DP all-reduce cover ~2 % of the parameters
-            assert not train_vision_tower and self.Hkv == self.l["heads"] and not self.l.get("qkv_bias")
+            assert not train_vision_tower
             r = self.lora["r"]
             self.lora_scale = self.lora.get("alpha", 16) / r
             self.lora_p = float(self.lora.get("dropout", 0.0))
@@ -446,7 +446,7 @@ class LlavaEngine:
             h1, rstd1 = ops.rmsnorm_fwd(x, lv["ln1"], self.eps)
             sv = {}
             if self.lora:
-                qkv = self._lora_linear(h1, lv["qkv"], i, self._MODS_QKV(d), sv)
+                qkv = self._lora_linear(h1, lv["qkv"], i, self._MODS_QKV(d), sv, bias=lv.get("bqkv"))   # frozen q/k/v biases (Qwen2)
             else:
                 qkv = ops.gemm_nt(h1, lv["qkv"], bias=lv.get("bqkv"))
             ops.rope_inplace(qkv, cs, S, H + Hkv, hd, 1, 1, positions=pos)   # q heads then k heads: one run of H + Hkv heads
@@ -520,16 +520,16 @@ class LlavaEngine:
         k = [t for t, _, _ in LORA_TARGETS].index(lname)
         return (self.lora_step * 1000003 + i * 131 + k) & 0x7FFFFFFFFFFFFFFF
 
-    @staticmethod
-    def _MODS_QKV(d):
-        return (("self_attn.q_proj", 0, d), ("self_attn.k_proj", d, 2 * d), ("self_attn.v_proj", 2 * d, 3 * d))
+    def _MODS_QKV(self, d):
+        kvd = self.kvd      # == d without grouped-query attention
+        return (("self_attn.q_proj", 0, d), ("self_attn.k_proj", d, d + kvd), ("self_attn.v_proj", d + kvd, d + 2 * kvd))
 
     def _lora_ws(self):
         if getattr(self, "_ws", None) is None:
             self._ws = torch.empty(32 << 20, dtype=torch.float32, device=self.device)   # split-K scratch (128 MiB)
         return self._ws
 
-    def _lora_linear(self, x, w, i, mods, saved, residual=None):
+    def _lora_linear(self, x, w, i, mods, saved, residual=None, bias=None):
         """y[:, c0:c1] = x W[c0:c1]^T + t B^T (+ residual) with t = (alpha/r) dropout(x) A^T: ONE launch per adapted module,
         the adapter rides the main GEMM as a second operand pair (K + r), no second pass over y."""
         y = torch.empty(x.shape[0], w.shape[0], dtype=BF16, device=self.device)
@@ -538,7 +538,8 @@ class LlavaEngine:
             A, B = self.W(pre + "lora_A.weight"), self.W(pre + "lora_B.weight")
             xd = ops.dropout(x, self.lora_p, self._lora_seed(i, lname)) if self.lora_p > 0 else x
             t = ops.gemm(xd, A, alpha=self.lora_scale)
-            ops.gemm(x, w[c0:c1], out=y[:, c0:c1], residual=None if residual is None else residual[:, c0:c1], a2=t, b2=B)
+            ops.gemm(x, w[c0:c1], out=y[:, c0:c1], bias=None if bias is None else bias[c0:c1],
+                     residual=None if residual is None else residual[:, c0:c1], a2=t, b2=B)
             saved[lname] = t
         return y
 

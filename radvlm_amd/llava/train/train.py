@@ -514,8 +514,6 @@ def train(attn_implementation=None, argv=None, tokenizer=None):
     is_qwen = "qwen" in mname or (model_args.geometry or "").find("qwen") >= 0
     name = model_args.geometry or ("llava_ov_qwen2_7b" if is_qwen else ("llava15_13b" if "13b" in mname else "llava15_7b"))
     Config, Model = (LlavaQwenConfig, LlavaQwenForCausalLM) if is_qwen else (LlavaConfig, LlavaLlamaForCausalLM)
-    if lora is not None and is_qwen:
-        raise NotImplementedError("LoRA on the Qwen2 decoder (grouped-query k/v, biases) is not built yet")
     cfg = Config(geometry=GEOMETRIES[name], mm_patch_merge_type=model_args.mm_patch_merge_type,
                       image_aspect_ratio=data_args.image_aspect_ratio, image_grid_pinpoints=data_args.image_grid_pinpoints,
                       tokenizer_model_max_length=training_args.model_max_length,

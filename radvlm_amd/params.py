@@ -72,10 +72,12 @@ def lora_trainable_shapes(geo, r, with_newline=False):
     s["model.mm_projector.2.bias"] = (l["d"],)
     if with_newline:
         s["model.image_newline"] = (l["d"],)
+    kvd = l["d"] // l["heads"] * l.get("kv_heads", l["heads"])      # grouped-query k/v projections are narrower (Qwen2)
     for i in range(l["layers"]):
         for t, o, k in LORA_TARGETS:
+            out = kvd if t in ("self_attn.k_proj", "self_attn.v_proj") else l[o]
             s[f"model.layers.{i}.{t}.lora_A.weight"] = (r, l[k])
-            s[f"model.layers.{i}.{t}.lora_B.weight"] = (l[o], r)
+            s[f"model.layers.{i}.{t}.lora_B.weight"] = (out, r)
     return s
 
 

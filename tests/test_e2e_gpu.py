@@ -271,16 +271,18 @@ def test_reference_api_surface_and_trainer(golden_dir, tmp_path):
     assert state["global_step"] == 3 and all(np.isfinite(r["loss"]) for r in state["log_history"])
 
 
-def test_toy_lora(golden_dir):
+@pytest.mark.parametrize("geo_name,golden", [("toy", "toy_e2e"), ("toy_qwen", "toy_qwen_e2e")])
+def test_toy_lora(golden_dir, geo_name, golden):
     """BASELINE config 5 path at toy size: frozen LM + LoRA adapters (r=8, alpha=16, dropout 0) + trainable projector,
-    against the oracle's LoRA restatement (parity unpinned upstream: peft absent, no reference fixtures)."""
+    against the oracle's LoRA restatement (parity unpinned upstream: peft absent, no reference fixtures).  The Qwen2 flavour has
+    narrower k/v adapters (grouped-query attention) and frozen q/k/v biases in the base."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from oracle import llava_oracle as O
     from radvlm_amd import portable_rng as prng
     from radvlm_amd.engine import LlavaEngine
-    geo = GEOMETRIES["toy"]
-    g, meta, images = _golden(golden_dir, "toy_e2e")
+    geo = GEOMETRIES[geo_name]
+    g, meta, images = _golden(golden_dir, golden)
     eng = LlavaEngine(geo, device="cuda:0", init="portable", seed=0, lora=dict(r=8, alpha=16, dropout=0.0))
     L = {}
     for n in eng.lm.names():
@@ -304,6 +306,8 @@ def test_toy_lora(golden_dir):
     assert abs(float(loss) - float(rl)) < 5e-3
     m = torch.from_numpy(g["splice_attention_mask"])
     assert float((logits[m] - rlog.detach()[m]).abs().max() / rlog.detach()[m].abs().max()) < 3e-2
+    if geo_name == "toy_qwen":
+        assert eng.lm.shapes["model.layers.0.self_attn.k_proj.lora_B.weight"] == (128, 8)      # kv_heads * head_dim = 2 * 64
     for n, ref in list(L.items()) + [(k, P[k]) for k in P if P[k].grad is not None]:
         got = eng.G(n).float().cpu()
         rel = float((got - ref.grad).norm() / ref.grad.norm().clamp_min(1e-8))
