@@ -167,7 +167,8 @@ int rv_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream
 /* ---- loss ----------------------------------------------------------------------------------------------------------
  * LlamaForCausalLM loss (modeling_llama.py:1323-1337): logits.float(), CE with ignore_index -100.
  * labels[r] is the ALREADY SHIFTED target of row r.  loss_rows[r] = -log softmax(logits[r])[label] (0 if ignored).
- * If dlogits != NULL: dlogits[r] = (softmax - onehot) * inv_count (0 rows if ignored); may alias logits. */
+ * If dlogits != NULL: dlogits[r] = (softmax - onehot) * inv_count (0 rows if ignored); may alias logits.
+ * V may be any size; rows are ld >= ceil8(V) wide, the pad columns are ignored on read and get zero gradient. */
 int rv_cross_entropy(const void* logits, int64_t ld, const int64_t* labels, float* loss_rows, void* dlogits,
                      int64_t ld_d, int rows, int V, float inv_count, void* stream);
 /* out[0] = scale * sum(in[0..n))  (deterministic, single block). */

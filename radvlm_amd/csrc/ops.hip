@@ -422,11 +422,13 @@ __global__ void gelu_tanh_bwd_kernel(const bf16* dy, const bf16* x, bf16* dx, lo
 // ------------------------------------------------------------------------------------------------ cross entropy
 __global__ __launch_bounds__(TPB) void cross_entropy_kernel(const bf16* logits, long ld, const int64_t* labels, float* loss_rows,
                                                             bf16* dlogits, long ld_d, int V, float inv_count) {
+    // V need not be a multiple of 8 (a vocabulary grown by a few special tokens): rows are padded to ld >= ceil8(V) columns, the
+    // pad columns are ignored on read (-inf) and their gradient is written as zero.
     __shared__ float red[8];
     const long row = blockIdx.x;
     const int64_t label = labels[row];
     const bf16* lr = logits + row * ld;
-    const int nvec = V / 8;
+    const int nvec = (V + 7) / 8;
     if (label < 0) {  // ignore_index
         if (threadIdx.x == 0) loss_rows[row] = 0.f;
         if (dlogits) {
@@ -439,6 +441,10 @@ __global__ __launch_bounds__(TPB) void cross_entropy_kernel(const bf16* logits, 
     for (int i = threadIdx.x; i < nvec; i += TPB) {
         float v[8];
         ld8(lr + i * 8, v);
+        if (i * 8 + 8 > V) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (i * 8 + j >= V) v[j] = -INFINITY;
+        }
         float vm = v[0];
 #pragma unroll
         for (int j = 1; j < 8; ++j) vm = fmaxf(vm, v[j]);
@@ -467,7 +473,7 @@ __global__ __launch_bounds__(TPB) void cross_entropy_kernel(const bf16* logits, 
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float p = __expf(v[j] - lse);
-                o[j] = (p - ((int64_t)(i * 8 + j) == label ? 1.f : 0.f)) * inv_count;
+                o[j] = (i * 8 + j < V) ? (p - ((int64_t)(i * 8 + j) == label ? 1.f : 0.f)) * inv_count : 0.f;
             }
             st8(dlogits + row * ld_d + i * 8, o);
         }
@@ -848,7 +854,7 @@ extern "C" int rv_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, v
 }
 extern "C" int rv_cross_entropy(const void* logits, int64_t ld, const int64_t* labels, float* loss_rows, void* dlogits, int64_t ld_d,
                                 int rows, int V, float inv_count, void* stream) {
-    if (!logits || !labels || !loss_rows || rows <= 0 || V <= 0 || (V & 7) || (ld & 7) || (dlogits && (ld_d & 7))) return RV_ERR_ARG;
+    if (!logits || !labels || !loss_rows || rows <= 0 || V <= 0 || (ld & 7) || ld < ((V + 7) & ~7) || (dlogits && ((ld_d & 7) || ld_d < ((V + 7) & ~7)))) return RV_ERR_ARG;
     hipLaunchKernelGGL(cross_entropy_kernel, dim3(rows), dim3(TPB), 0, ST, (const bf16*)logits, (long)ld, labels, loss_rows, (bf16*)dlogits, (long)ld_d, V, inv_count);
     return rv_check_launch();
 }

@@ -46,6 +46,8 @@ class LlavaEngine:
         self.max_len = max_len
         self.eps = self.l.get("rms_eps", rms_eps)
         self.theta = self.l.get("rope_theta", rope_theta)
+        self.vocab = self.l["vocab"]                                # logical vocabulary (the tables may hold up to 7 zero pad rows)
+        assert self.vocab % 8 == 0, "built-in geometries keep the vocabulary a multiple of 8; grow it with resize_token_embeddings"
         self.hd = self.l["d"] // self.l["heads"]
         self.Hkv = self.l.get("kv_heads", self.l["heads"])       # grouped-query attention (Qwen2)
         self.kvd = self.Hkv * self.hd
@@ -113,6 +115,45 @@ class LlavaEngine:
         self.sync = FlatGradSync(self.grads, process_group) if self.world > 1 else None
         self.ctx = None
         self.grad_accum_started = False
+
+    # ------------------------------------------------------------------ vocabulary
+    def resize_token_embeddings(self, new_vocab):
+        """resize_token_embeddings + the mean initialisation of initialize_vision_tokenizer (llava_arch.py:563-575): embed_tokens and
+        lm_head grow to `new_vocab` rows, the added rows start as the mean of the existing ones.  The flat parameter / gradient
+        buffers are rebuilt (every other tensor is copied bit for bit) and the optimizer state restarts."""
+        old_v = self.vocab
+        if new_vocab == old_v:
+            return
+        assert new_vocab > old_v and not self.lora, "growing a full (non-LoRA) model only"
+        import copy
+        from collections import OrderedDict
+        phys = _ru(int(new_vocab), 8)        # table rows: a multiple of 8 (GEMM / CE vector width); rows >= new_vocab stay exactly zero
+        geo = copy.deepcopy(self.geo)
+        geo["lm"]["vocab"] = phys
+        shapes = OrderedDict(vision_param_shapes(geo)) if self.train_tower else OrderedDict()
+        shapes.update(lm_param_shapes(geo, self.with_newline))
+        new = FlatParams(shapes, self.device)
+        for name in self.lm.names():
+            src, dst = self.lm.view(name), new.view(name)
+            if name in ("model.embed_tokens.weight", "lm_head.weight"):
+                dst[:old_v].copy_(src[:old_v])
+                dst[old_v:new_vocab].copy_(src[:old_v].float().mean(dim=0, keepdim=True).to(BF16).expand(new_vocab - old_v, -1))
+            else:
+                dst.copy_(src)
+        self.vocab = int(new_vocab)
+        tower_shared = self.vis is self.lm
+        self.geo, self.l, self.v = geo, geo["lm"], geo["vision"]
+        self.lm = new
+        if tower_shared:
+            self.vis = new
+        self.grads = new.like(BF16)
+        self.master = self.m = self.vv = None
+        self.opt_step = 0
+        self.grad_accum_started = False
+        if self.world > 1:
+            from .ddp import FlatGradSync
+            self.sync = FlatGradSync(self.grads, self.pg)
+        self.weights_changed()
 
     # ------------------------------------------------------------------ weights
     def W(self, name):
@@ -482,12 +523,12 @@ class LlavaEngine:
         if want_logits and packed:      # callers see the reference's padded [B, S, V] shape (padding rows zero)
             logits_out = torch.zeros(B * S, V, dtype=torch.float32, device=dev)
             logits_out[torch.from_numpy(valid_idx).to(dev)] = ops.to_f32(logits)
-            logits_out = logits_out.view(B, S, V)
+            logits_out = logits_out.view(B, S, V)[..., :self.vocab]
         elif want_logits:
-            logits_out = ops.to_f32(logits).view(B, S, V)
+            logits_out = ops.to_f32(logits).view(B, S, V)[..., :self.vocab]
         # CE writes dlogits (scaled by loss_scale/count/world) over the logits buffer
         gscale = loss_scale / self.world
-        loss, _ = self._cross_entropy(logits, tgt_t, V, inv, gscale)
+        loss, _ = self._cross_entropy(logits, tgt_t, self.vocab, inv, gscale)   # V = table rows (pad rows included), CE sees the logical vocabulary
         ctx.update(B=B, S=S, M=M, s_pad=s_pad, lens=lens, cu=cu, pos=pos, layers=layers, x_last=x, rstdN=rstdN, hN=hN, dlogits=logits,
                    table_rows=table.shape[0], count=count)
         self.ctx = ctx
@@ -741,7 +782,7 @@ class LlavaEngine:
         out = {}
         for fp in ((self.lm,) if self.vis is self.lm else (self.lm, self.vis)):
             for n in fp.names():
-                out[n] = fp.view(n)
+                out[n] = fp.view(n)[:self.vocab] if n in ("model.embed_tokens.weight", "lm_head.weight") else fp.view(n)
         return out
 
     def lora_state_dict(self):

@@ -181,9 +181,20 @@ class LlavaLlamaForCausalLM:
         return e.encode_images(x.contiguous())[:x.shape[0] * e.P].view(x.shape[0], e.P, e.l["d"])
 
     def initialize_vision_tokenizer(self, model_args, tokenizer):
-        """llava_arch.py:557-597: only the no-extra-token configuration of LLaVA-1.5 is on the hot path."""
+        """llava_arch.py:557-597: optional <im_patch> / <im_start>, <im_end> tokens are added to the tokenizer and the embedding
+        tables grow by as many rows, initialised to the mean of the existing rows (full fine-tuning; the projector-only variants
+        that flip requires_grad on the embeddings, :577-581 / :593-597, belong to the pretraining stage and are not built)."""
+        from ..constants import DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN, DEFAULT_IMAGE_PATCH_TOKEN
+        if getattr(model_args, "mm_use_im_patch_token", False):
+            tokenizer.add_tokens([DEFAULT_IMAGE_PATCH_TOKEN], special_tokens=True)
+            self.engine.resize_token_embeddings(max(len(tokenizer), self.engine.l["vocab"]))
         if getattr(model_args, "mm_use_im_start_end", False):
-            raise NotImplementedError("mm_use_im_start_end adds trainable token rows; outside the hot path")
+            if getattr(model_args, "tune_mm_mlp_adapter", False):
+                raise NotImplementedError("tune_mm_mlp_adapter with mm_use_im_start_end (pretraining stage)")
+            tokenizer.add_tokens([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN], special_tokens=True)
+            self.engine.resize_token_embeddings(max(len(tokenizer), self.engine.l["vocab"]))
+            self.config.vocab_size = self.engine.l["vocab"]
+        self.config.mm_use_im_start_end = bool(getattr(model_args, "mm_use_im_start_end", False))
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None, labels=None,
                 use_cache=None, output_attentions=None, output_hidden_states=None, images=None, image_sizes=None, return_dict=None,

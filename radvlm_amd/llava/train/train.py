@@ -529,6 +529,11 @@ def train(attn_implementation=None, argv=None, tokenizer=None):
         import transformers
         tokenizer = transformers.AutoTokenizer.from_pretrained(model_args.model_name_or_path, cache_dir=training_args.cache_dir,
                                                                 model_max_length=training_args.model_max_length, padding_side="right", use_fast=False)
+    # train/train.py:1678-1679: optional extra tokens grow the embedding tables (needs a tokenizer with add_tokens / __len__;
+    # the RadVLM script passes --mm_use_im_patch_token False and no start/end tokens, so this is normally a no-op)
+    model.config.mm_use_im_patch_token = model_args.mm_use_im_patch_token
+    if hasattr(tokenizer, "add_tokens") and (model_args.mm_use_im_start_end or model_args.mm_use_im_patch_token):
+        model.initialize_vision_tokenizer(model_args, tokenizer=tokenizer)
     side = cfg.geometry["vision"]["image"]
     if cfg.geometry["vision"].get("kind") == "siglip":
         data_args.image_processor = SigLipImageProcessor(size=(side, side), crop_size={"height": side, "width": side})

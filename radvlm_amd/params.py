@@ -191,7 +191,11 @@ def load_named(fp: FlatParams, state_dict, strict=False):
     for k, t in state_dict.items():
         ck = canonical_name(k)
         if ck in fp.offsets:
-            fp.view(ck).copy_(t.to(fp.flat.dtype).reshape(fp.shapes[ck]))
+            dst = fp.view(ck)
+            if t.ndim == 2 and t.shape[0] < dst.shape[0] and t.shape[1:] == dst.shape[1:]:
+                dst[:t.shape[0]].copy_(t.to(fp.flat.dtype))     # vocabulary tables padded to a multiple of 8 rows
+            else:
+                dst.copy_(t.to(fp.flat.dtype).reshape(fp.shapes[ck]))
             seen.add(ck)
         else:
             unexpected.append(k)

@@ -633,3 +633,59 @@ def test_edge_cases_against_oracle(packed):
     for k in ("model.embed_tokens.weight", "model.mm_projector.2.weight", "model.layers.0.self_attn.q_proj.weight", "lm_head.weight"):
         got, want = eng.G(k).float().cpu(), P[k].grad
         assert float((got - want).norm() / want.norm()) < 5e-2, k
+
+
+def test_vocab_growth_for_extra_image_tokens(golden_dir):
+    """initialize_vision_tokenizer (llava_arch.py:557-597): <im_start>/<im_end> rows appended to embed_tokens / lm_head as the mean of the
+    existing rows, every other tensor untouched; the grown model still matches the oracle (which sees the grown tables)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import sys
+    from types import SimpleNamespace
+    from oracle import llava_oracle as O
+    sys.path.insert(0, golden_dir)
+    import toy_chatml_tokenizer as T
+    from radvlm_amd.llava.model import LlavaConfig, LlavaLlamaForCausalLM
+    g, meta, images = _golden(golden_dir, "toy_e2e")
+    model = LlavaLlamaForCausalLM(LlavaConfig(geometry=GEOMETRIES["toy"]), device="cuda:0", init="portable")
+    eng = model.engine
+    before = {k: v.clone() for k, v in eng.state_dict().items()}
+    tok = T.build()
+    n0 = len(tok)
+    model.initialize_vision_tokenizer(SimpleNamespace(mm_use_im_patch_token=False, mm_use_im_start_end=True, tune_mm_mlp_adapter=False), tok)
+    assert len(tok) == n0 + 2 and eng.l["vocab"] == 1000          # the toy tokenizer (202 ids) still fits the 1000-row tables: no growth
+    eng.resize_token_embeddings(1002)
+    after = eng.state_dict()
+    assert eng.vocab == 1002 and eng.l["vocab"] == 1008 and after["lm_head.weight"].shape[0] == 1002      # tables padded to 8 rows, exported unpadded
+    assert float(eng.W("lm_head.weight")[1002:].float().abs().max()) == 0.0
+    assert GEOMETRIES["toy"]["lm"]["vocab"] == 1000                # the shared geometry table is not mutated
+    for k, v in before.items():
+        if k in ("model.embed_tokens.weight", "lm_head.weight"):
+            assert torch.equal(after[k][:1000], v)
+            mean = v.float().mean(0).to(torch.bfloat16)
+            assert torch.equal(after[k][1000], mean) and torch.equal(after[k][1001], mean)
+        else:
+            assert torch.equal(after[k], v), k
+    ids = g["input_ids"].copy()
+    ids[0, 1], ids[1, 0] = 1000, 1001                               # use the new rows
+    labels = g["labels"].copy()
+    labels[0, 1] = 1000
+    loss = eng.forward(ids, g["attention_mask"], labels, images, want_logits=True)
+    assert tuple(eng.last_logits.shape)[-1] == 1002
+    eng.backward()
+    torch.cuda.synchronize()
+    geo2 = {"vision": GEOMETRIES["toy"]["vision"], "lm": dict(GEOMETRIES["toy"]["lm"], vocab=1002)}
+    P = {k: v.float().cpu() for k, v in after.items()}
+    for k in P:
+        if "vision_tower" not in k:
+            P[k].requires_grad_(True)
+    rl, rlog, aux = O.llava_forward(P, geo2, torch.from_numpy(ids), torch.from_numpy(g["attention_mask"]), torch.from_numpy(labels), images)
+    rl.backward()
+    assert abs(float(loss) - float(rl)) < 5e-3
+    ge, we = eng.G("model.embed_tokens.weight").float().cpu(), P["model.embed_tokens.weight"].grad
+    assert float((ge[1000:1002] - we[1000:]).norm() / we[1000:].norm()) < 5e-2 and float(we[1000:].norm()) > 0
+    assert float(ge[1002:].abs().max()) == 0.0 and float(eng.G("lm_head.weight").float()[1002:].abs().max()) == 0.0   # pad rows: zero gradient
+    eng.optimizer_step(lr=1e-3, weight_decay=0.1, max_grad_norm=1.0)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(eng.lm.flat.float()).all())
+    assert float(eng.W("lm_head.weight")[1002:].float().abs().max()) == 0.0 and float(eng.W("model.embed_tokens.weight")[1002:].float().abs().max()) == 0.0
