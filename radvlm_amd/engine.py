@@ -33,7 +33,7 @@ def _ru(x, m):
 class LlavaEngine:
     def __init__(self, geo, device="cuda", merge_type="flat", image_aspect_ratio="square", image_grid_pinpoints=None,
                  max_len=None, init="portable", seed=0, rms_eps=1e-5, rope_theta=10000.0, process_group=None,
-                 bucket_layers=1, train_vision_tower=False, lora=None, packed="auto"):
+                 bucket_layers=1, train_vision_tower=False, lora=None, packed="auto", freeze_lm=False):
         self.geo = geo
         # packed (varlen) decoder batches: True / False / "auto" (pack when the samples of a batch differ in length): the decoder
         # then runs on sum(len_b) token rows instead of B * max(len_b) -- no padding rows through GEMMs, norms, CE
@@ -65,6 +65,7 @@ class LlavaEngine:
         self.kp = _ru(3 * self.v["patch"] ** 2, 8)
         self.train_tower = train_vision_tower
         self.lora = dict(lora) if lora else None   # {"r": 64, "alpha": 16, "dropout": 0.05}
+        self.freeze_lm = bool(freeze_lm) and not self.lora
         self.base = None
         if self.lora:
             # LoRA (BASELINE config 5): the language model is a frozen bf16 store; only adapters + projector are
@@ -75,6 +76,16 @@ class LlavaEngine:
             self.lora_p = float(self.lora.get("dropout", 0.0))
             self.base = FlatParams(lm_param_shapes(geo, False), self.device)
             self.lm = FlatParams(lora_trainable_shapes(geo, r, self.with_newline), self.device)
+            self.vis = FlatParams(vision_param_shapes(geo), self.device)
+        elif freeze_lm:
+            # projector-only stage (tune_mm_mlp_adapter / mm_tunable_parts="mm_mlp_adapter", train/train.py:1613-1640): tower and
+            # language model are frozen stores; the trainable flat buffer holds the projector (+ image_newline) alone -- the
+            # backward computes input gradients through the frozen decoder and no weight gradients for it
+            assert not train_vision_tower
+            from collections import OrderedDict
+            full = lm_param_shapes(geo, self.with_newline)
+            self.base = FlatParams(lm_param_shapes(geo, False), self.device)
+            self.lm = FlatParams(OrderedDict((k, v) for k, v in full.items() if "mm_projector" in k or k == "model.image_newline"), self.device)
             self.vis = FlatParams(vision_param_shapes(geo), self.device)
         elif train_vision_tower:
             # mm_tunable_parts contains mm_vision_tower (train/train.py:1658-1661): the tower joins the trainable flat
@@ -626,7 +637,7 @@ class LlavaEngine:
         acc = self.grad_accum_started
         cs = self.rope_table(S)
         # head
-        frozen_lm = self.lora is not None
+        frozen_lm = self.base is not None          # LoRA or projector-only: the decoder weights receive no gradients
         dhN = self._linear_bwd(c["dlogits"], c["hN"], self.W("lm_head.weight"), None if frozen_lm else self.G("lm_head.weight"))
         dx, _ = ops.rmsnorm_bwd(dhN, c["x_last"], self.W("model.norm.weight"), c["rstdN"],
                                 dw=None if frozen_lm else self.G("model.norm.weight"), dw_accumulate=acc)
@@ -653,7 +664,9 @@ class LlavaEngine:
             ops.rmsnorm_bwd(dh1, a["x"], lv["ln1"], a["rstd1"], dx=dx, dx_add=True, dw=gv.get("ln1"), dw_accumulate=acc)
             c["layers"][i] = None  # free this layer's activations
             p = f"model.layers.{i}."
-            if frozen_lm:
+            if self.freeze_lm:
+                pass                        # nothing trainable inside the layer
+            elif frozen_lm:
                 self._bucket_done(p + "self_attn.q_proj.lora_A.weight", p + "mlp.down_proj.lora_B.weight")
             else:
                 self._bucket_done(p + "input_layernorm.weight", p + "mlp.down_proj.weight")
@@ -779,9 +792,14 @@ class LlavaEngine:
 
     # ------------------------------------------------------------------ state dict (reference names)
     def state_dict(self):
+        """Every tensor under its reference name: trainable buffer, frozen tower and -- for LoRA / projector-only runs -- the frozen
+        language-model store (adapters keep their .lora_A/.lora_B names; lora_state_dict() gives peft's layout)."""
         out = {}
-        for fp in ((self.lm,) if self.vis is self.lm else (self.lm, self.vis)):
+        stores = [self.lm] + ([] if self.vis is self.lm else [self.vis]) + ([self.base] if self.base is not None else [])
+        for fp in stores:
             for n in fp.names():
+                if n in out:
+                    continue        # the projector lives in the trainable buffer; the base store's copy of it is unused
                 out[n] = fp.view(n)[:self.vocab] if n in ("model.embed_tokens.weight", "lm_head.weight") else fp.view(n)
         return out
 
@@ -799,12 +817,15 @@ class LlavaEngine:
 
     def load_state_dict(self, sd, strict=False):
         from .params import load_named
-        m1, u1 = load_named(self.lm, sd)
-        m2, u2 = ([], u1) if self.vis is self.lm else load_named(self.vis, {k: v for k, v in sd.items() if k in u1})
+        missing, rest = load_named(self.lm, sd)
+        for fp in ([] if self.vis is self.lm else [self.vis]) + ([self.base] if self.base is not None else []):
+            m, rest2 = load_named(fp, {k: v for k, v in sd.items() if k in rest})
+            if fp is self.base:     # the base store also has projector slots (unused): not "missing"
+                m = [k for k in m if k not in self.lm.offsets]
+            missing, rest = missing + m, rest2
         self.weights_changed()
         if self.master is not None:
             self.master.copy_(ops.to_f32(self.lm.flat))
-        missing, unexpected = m1 + m2, u2
-        if strict and (missing or unexpected):
-            raise KeyError(f"missing={missing[:4]} unexpected={unexpected[:4]}")
-        return missing, unexpected
+        if strict and (missing or rest):
+            raise KeyError(f"missing={missing[:4]} unexpected={rest[:4]}")
+        return missing, rest

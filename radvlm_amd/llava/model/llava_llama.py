@@ -145,7 +145,7 @@ class LlavaLlamaForCausalLM:
                                   max_len=config.tokenizer_model_max_length, init=init, seed=seed, rms_eps=config.rms_norm_eps,
                                   rope_theta=config.rope_theta, process_group=process_group,
                                   train_vision_tower=getattr(config, "unfreeze_mm_vision_tower", False),
-                                  lora=getattr(config, "lora", None))
+                                  lora=getattr(config, "lora", None), freeze_lm=getattr(config, "freeze_lm", False))
         self.model = self.model_class(self.engine, config)
         self.training = True
         # a leaf that makes loss require grad so that `.backward()` reaches the engine

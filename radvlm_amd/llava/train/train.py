@@ -502,8 +502,9 @@ def train(attn_implementation=None, argv=None, tokenizer=None):
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
         pg = torch.distributed.group.WORLD
     parts = tunable_parts(model_args)
-    if parts - {"mm_vision_tower"} != {"mm_mlp_adapter", "mm_language_model"}:
-        raise NotImplementedError(f"tunable parts {sorted(parts)}: the projector and the language model are always trained here")
+    projector_only = parts == {"mm_mlp_adapter"}      # tune_mm_mlp_adapter / mm_tunable_parts="mm_mlp_adapter": the pretraining stage
+    if not projector_only and parts - {"mm_vision_tower"} != {"mm_mlp_adapter", "mm_language_model"}:
+        raise NotImplementedError(f"tunable parts {sorted(parts)}: supported are projector only, projector + LM, projector + LM + tower")
     lora = None
     if training_args.lora_enable:   # peft LoraConfig(r, lora_alpha, lora_dropout, bias="none") on every LM linear (train.py:1515-1532)
         if training_args.lora_bias != "none" or "mm_vision_tower" in parts:
@@ -517,7 +518,7 @@ def train(attn_implementation=None, argv=None, tokenizer=None):
     cfg = Config(geometry=GEOMETRIES[name], mm_patch_merge_type=model_args.mm_patch_merge_type,
                       image_aspect_ratio=data_args.image_aspect_ratio, image_grid_pinpoints=data_args.image_grid_pinpoints,
                       tokenizer_model_max_length=training_args.model_max_length,
-                      unfreeze_mm_vision_tower="mm_vision_tower" in parts, lora=lora)
+                      unfreeze_mm_vision_tower="mm_vision_tower" in parts, lora=lora, freeze_lm=projector_only)
     model = Model(cfg, device=f"cuda:{local}", process_group=pg, init="fast")
     model.config.use_cache = False
     model.get_model().initialize_vision_modules(model_args)

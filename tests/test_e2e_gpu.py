@@ -689,3 +689,37 @@ def test_vocab_growth_for_extra_image_tokens(golden_dir):
     torch.cuda.synchronize()
     assert bool(torch.isfinite(eng.lm.flat.float()).all())
     assert float(eng.W("lm_head.weight")[1002:].float().abs().max()) == 0.0 and float(eng.W("model.embed_tokens.weight")[1002:].float().abs().max()) == 0.0
+
+
+def test_projector_only_stage_and_state_dict_round_trip(golden_dir):
+    """tune_mm_mlp_adapter / mm_tunable_parts='mm_mlp_adapter' (train/train.py:1613-1640): tower and decoder frozen, gradients and optimizer
+    state for the projector alone -- same loss and projector gradients as the full run; the full state dict (frozen stores included)
+    round-trips through load_state_dict, also into a LoRA engine's frozen base."""
+    from radvlm_amd.engine import LlavaEngine
+    g, meta, images = _golden(golden_dir, "toy_e2e")
+    eng = _engine("toy", freeze_lm=True)
+    assert eng.lm.names() == ["model.mm_projector.0.weight", "model.mm_projector.0.bias", "model.mm_projector.2.weight", "model.mm_projector.2.bias"]
+    assert eng.grads.numel() < 0.1 * eng.base.numel
+    loss, logits, plan = _run(eng, g, images)
+    assert abs(loss - float(g["loss"])) < 5e-3
+    for k in eng.lm.names():
+        want = meta["grad_norms"][k]
+        assert abs(float(eng.G(k).float().norm()) - want) < 5e-2 * want, k
+    ref = torch.from_numpy(g["grad::model.mm_projector.0.weight"])
+    assert float((eng.G("model.mm_projector.0.weight").float().cpu() - ref).norm() / ref.norm()) < 5e-2
+    lm_before = eng.base.flat.clone()
+    proj_before = eng.lm.flat.clone()
+    eng.optimizer_step(lr=1e-3, max_grad_norm=1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.base.flat, lm_before) and not torch.equal(eng.lm.flat, proj_before)
+    sd = {k: v.clone() for k, v in eng.state_dict().items()}
+    assert "model.layers.1.mlp.down_proj.weight" in sd and "lm_head.weight" in sd and "model.mm_projector.2.bias" in sd
+    full = LlavaEngine(GEOMETRIES["toy"], device="cuda:0", init="fast", seed=9)
+    missing, unexpected = full.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    for k, v in sd.items():
+        assert torch.equal(full.state_dict()[k], v), k
+    lora = LlavaEngine(GEOMETRIES["toy"], device="cuda:0", init="fast", seed=5, lora=dict(r=8, alpha=16, dropout=0.0))
+    missing, unexpected = lora.load_state_dict(sd)
+    assert all(".lora_" in k for k in missing) and not unexpected
+    assert torch.equal(lora.base.view("model.layers.0.self_attn.q_proj.weight"), sd["model.layers.0.self_attn.q_proj.weight"])
