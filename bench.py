@@ -133,31 +133,39 @@ class GemmTimer:
         self.records = []
         self.depth = 0
 
-    def _timed(self, fn, flops, *args, **kw):
+    def _timed(self, fn, flops, abytes, *args, **kw):
         if self.depth:                      # gemm_nt forwards to gemm: count a launch once
             return fn(*args, **kw)
         self.depth += 1
         try:
-            return self._timed1(fn, flops, *args, **kw)
+            return self._timed1(fn, flops, abytes, *args, **kw)
         finally:
             self.depth -= 1
 
-    def _timed1(self, fn, flops, *args, **kw):
+    def _timed1(self, fn, flops, abytes, *args, **kw):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         out = fn(*args, **kw)
         e1.record()
-        self.records.append((flops, e0, e1))
+        # algorithmic bytes of the launch: every operand read once, the output written once
+        abytes += out.numel() * out.element_size()
+        for k in ("residual", "bias", "a2", "b2"):
+            t = kw.get(k)
+            if t is not None:
+                abytes += t.numel() * t.element_size()
+        self.records.append((flops, e0, e1, abytes))
         return out
 
     def __enter__(self):
+        nbytes = lambda t: t.numel() * t.element_size()
+
         def nt(a, b, *args, **kw):
-            return self._timed(self.orig_nt, 2.0 * a.shape[0] * b.shape[0] * a.shape[1], a, b, *args, **kw)
+            return self._timed(self.orig_nt, 2.0 * a.shape[0] * b.shape[0] * a.shape[1], nbytes(a) + nbytes(b), a, b, *args, **kw)
 
         def gen(a, b, ta=False, tb=False, **kw):
             k, m = a.shape if ta else a.shape[::-1]
             n = b.shape[1] if tb else b.shape[0]
-            return self._timed(self.orig, 2.0 * m * n * k, a, b, ta=ta, tb=tb, **kw)
+            return self._timed(self.orig, 2.0 * m * n * k, nbytes(a) + nbytes(b), a, b, ta=ta, tb=tb, **kw)
         self.ops.gemm_nt, self.ops.gemm = nt, gen
         return self
 
@@ -168,7 +176,7 @@ class GemmTimer:
         torch.cuda.synchronize()
         flops = sum(r[0] for r in self.records)
         ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
-        return flops, ms, len(self.records)
+        return flops, ms, len(self.records), sum(r[3] for r in self.records)
 
 
 def main():
@@ -185,7 +193,22 @@ def main():
     ap.add_argument("--lr", type=float, default=2e-5)
     ap.add_argument("--text-lens", default=None, help="lo,hi: variable per-sample text lengths (cxr workload only; not the BASELINE workload)")
     ap.add_argument("--packed", default="auto", choices=["auto", "0", "1"], help="packed (varlen) decoder batches")
+    ap.add_argument("--reserved-cus", type=int, default=None,
+                    help="compute units the GEMM round planning leaves to the overlapped RCCL all-reduce (default 0: the collectives are active for a small part of backward only)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU over RCCL), BEFORE anything touches the
+        # GPU -- no HIP library is loaded and no torch.cuda call has run in this process -- as a child process whose exit code
+        # becomes ours (never exec: a process that has initialised the GPU must not be replaced)
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
 
     from radvlm_amd import lib, ops
     from radvlm_amd.config import GEOMETRIES
@@ -196,7 +219,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus N` or torchrun --nproc-per-node N")
     # rehearsal hook (tests only): RV_BENCH_REHEARSAL=1 runs all ranks on cuda:0 over gloo, because RCCL refuses two
     # ranks on one device and the multi-GPU node is the driver's; the measured path always uses nccl (= RCCL)
     rehearsal = os.environ.get("RV_BENCH_REHEARSAL") == "1"
@@ -210,6 +234,16 @@ def main():
         else:
             torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
         pg = torch.distributed.group.WORLD
+    ranks_seen, backend = 1, None
+    if world > 1:
+        seen = torch.zeros(world, dtype=torch.int32, device=f"cuda:{local}")
+        seen[rank] = 1
+        torch.distributed.all_reduce(seen)
+        ranks_seen, backend = int(seen.sum()), torch.distributed.get_backend()
+        assert ranks_seen == world, f"{ranks_seen} of {world} ranks answered"
+    # GEMM round planning budget: the device's CU count minus what --reserved-cus leaves to the RCCL kernels that run beside backward
+    reserved = args.reserved_cus if args.reserved_cus is not None else int(os.environ.get("RV_GEMM_RESERVED_CUS", "0"))
+    cu_budget = lib.load().rv_gemm_set_cu_budget(0, reserved)
     geo = GEOMETRIES[args.geometry]
     kw = {}
     if args.workload == "anyres":
@@ -257,26 +291,48 @@ def main():
     pairs = args.batch * world * args.steps
     value = pairs / dt
 
+    # exposed communication: time the compute stream spends waiting for the last gradient buckets (events around finish_grad_sync)
+    comm_wait_ms = None
+    if eng.sync is not None:
+        eng.sync.timing = []
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        comm_wait_ms = sum(a.elapsed_time(b) for a, b in eng.sync.timing) / 2
+        eng.sync.timing = None
+
     # dominant kernel (bf16 MFMA GEMM): algorithmic flops / measured launch time, one extra instrumented step
     with GemmTimer(ops) as gt:
         step()
-        gflops, gms, nlaunch = gt.summary()
+        gflops, gms, nlaunch, gbytes = gt.summary()
+    from radvlm_amd.build_id import kernel_source_sha256
+    src_hash = kernel_source_sha256()
     roofline = {"bound": "mfma", "kernel": "gemm_kernel_256 (all operand forms; 128x128 kernel for small shapes)", "achieved": gflops / (gms * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS,
                 "unit": "TFLOP/s", "traffic": None, "launches_per_step": nlaunch, "gemm_ms_per_step": gms,
-                "algorithmic_flops_per_launch": gflops / max(1, nlaunch), "avg_launch_us": gms * 1e3 / max(1, nlaunch)}
+                "algorithmic_flops_per_launch": gflops / max(1, nlaunch), "algorithmic_bytes_per_launch": gbytes / max(1, nlaunch),
+                "avg_launch_us": gms * 1e3 / max(1, nlaunch)}
     roofline["frac"] = roofline["achieved"] / roofline["peak"]
-    try:  # HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE)
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm_hbm_traffic.json")) as f:
-            roofline["traffic"] = json.load(f)["gemm_kernel_256"]["hbm_bytes_per_launch"] if args.workload == "cxr" and args.batch == 32 else None
-        roofline["traffic_source"] = "profiles/r01_pmc_gemm_hbm_traffic.json (separate --pmc passes of this command)"
-    except OSError:
-        pass
-    try:  # MFMA-pipe busy fraction and held clock of the GEMM launches (separate rocprofv3 --pmc pass, tools/pmc_mfma_summary.py)
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_mfma_util.json")) as f:
-            if args.workload == "cxr" and args.batch == 32:
-                roofline["pmc_mfma"] = json.load(f)["gemm_kernel_256_all_forms"]
-    except OSError:
-        pass
+    # counter-derived fields come from separate `rocprofv3 --pmc` passes of this very command (profiles/README.md); they are quoted
+    # only when they were taken on the kernel sources this run uses (radvlm_amd.build_id) and for the same workload -- else null
+    headline = args.workload == "cxr" and args.batch == 32 and args.geometry == "llava15_7b" and not args.text_lens
+
+    def pmc(name):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            return None
+        return d if (headline and d.get("kernel_source_sha256") == src_hash) else None
+    tr = pmc("r02_pmc_gemm_hbm_traffic.json")
+    if tr:
+        roofline["traffic"] = tr["gemm_kernel_256"]["hbm_bytes_per_launch"]
+        roofline["traffic_over_algorithmic"] = roofline["traffic"] / roofline["algorithmic_bytes_per_launch"]
+        roofline["traffic_source"] = f"profiles/r02_pmc_gemm_hbm_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command, kernel sources {src_hash})"
+    else:
+        roofline["traffic_source"] = f"null: no PMC pass on record for kernel sources {src_hash} / this workload"
+    mf = pmc("r02_pmc_mfma_util.json")
+    if mf:
+        roofline["pmc_mfma"] = mf["gemm_kernel_256_all_forms"]
     tf_pair = TF_PER_PAIR.get(args.geometry) if args.workload == "cxr" else None
     if tf_pair:
         roofline["step_algorithmic_tflops"] = tf_pair * args.batch / (ms_per_step * 1e-3)
@@ -296,6 +352,10 @@ def main():
                        "parallelism": f"dp{world}", "final_loss": final_loss,
                        **({"text_lens": args.text_lens, "packed": args.packed} if args.text_lens else {})},
             "roofline": roofline,
+            "distributed": {"world": world, "ranks_seen": ranks_seen, "backend": backend if not rehearsal else f"{backend} (rehearsal: all ranks on one GPU)",
+                            "grad_sync": None if world == 1 else "bucketed sum-all-reduce of the flat bf16 gradient buffer, per-layer buckets on a side stream",
+                            "exposed_comm_ms_per_step": comm_wait_ms, "gemm_cu_budget": cu_budget, "reserved_cus": reserved},
+            "build": {"kernel_source_sha256": src_hash},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(geo)

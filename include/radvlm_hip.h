@@ -5,7 +5,10 @@
  * (file:line under /root/reference/finetuning/llava, or HF: = transformers as pinned by the reference) whose
  * arithmetic it replaces.  Conventions for every function:
  *   - plain device pointers + sizes, no torch types; bf16 = raw uint16 storage; strides (ld*) in ELEMENTS;
- *   - asynchronous on `stream` (a hipStream_t), no allocation, no host sync, no global state (except the rv_gemm_select_kernel measurement hook);
+ *   - asynchronous on `stream` (a hipStream_t), no allocation, no host sync;
+ *   - no state that depends on a call's arguments.  What the library does keep, per process (one process drives one GPU): the
+ *     GEMM launch configuration (CU budget, rv_gemm_set_cu_budget; tile-selection hook, rv_gemm_select_kernel) and "dynamic LDS
+ *     size attribute already set" flags per kernel instantiation.  Results never depend on it, only the launch shape does;
  *   - `zeros16` is any 16-byte-aligned device buffer of >= 16 zero bytes (source for out-of-range tile chunks);
  *   - returns 0 (RV_OK) or a negative error code (RV_ERR_*), which the Python binding raises as an exception.
  */
@@ -55,9 +58,15 @@ int rv_gemm_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void
                     const void* residual, int64_t ldr, int M, int N, int K, int trans_a, int trans_b, float alpha, int act,
                     int out_f32, int res_f32, const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int K2,
                     void* workspace, int64_t workspace_bytes, const void* zeros16, void* stream);
-/* Measurement hook, the ONE piece of process-global state in the library (A/B tools and tests only; the product path never
- * calls it): 0 = automatic tile selection (default), 1 = 128x128 tile kernel, 2 = 256x256 tile kernel, 20 / 21 = tail split off / on. */
+/* Measurement hook (A/B tools and tests only; the product path never calls it): 0 = automatic tile selection (default),
+ * 1 = 128x128 tile kernel, 2 = 256x256 tile kernel, 20 / 21 = tail split off / on.  Process-wide. */
 int rv_gemm_select_kernel(int which);
+/* Compute units the GEMM plans its tile rounds for (whole rounds of one 256x256 tile per CU, the K-split of a half-empty last
+ * round, split-K of small outputs).  total_cus <= 0: the current device's multiProcessorCount (256 on MI355X); reserved_cus:
+ * units left to concurrently running work -- the bucketed RCCL all-reduce that overlaps backward in data-parallel runs
+ * (what DDP's NCCL kernels take on the reference's GPUs).  Default without a call: all units, or
+ * RV_GEMM_RESERVED_CUS from the environment.  Returns the resulting budget (>= 8) or a negative error code.  Process-wide. */
+int rv_gemm_set_cu_budget(int total_cus, int reserved_cus);
 
 /* Batched strided transpose of bf16 matrices: out[bz][c][r] = in[bz][r][c], r < R, c < C; columns r in [R, R_pad)
  * of every output row are written as zero.  bz = b0 * nb1 + b1; offsets in elements.
@@ -167,7 +176,9 @@ int rv_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream
 /* ---- loss ----------------------------------------------------------------------------------------------------------
  * LlamaForCausalLM loss (modeling_llama.py:1323-1337): logits.float(), CE with ignore_index -100.
  * labels[r] is the ALREADY SHIFTED target of row r.  loss_rows[r] = -log softmax(logits[r])[label] (0 if ignored).
- * If dlogits != NULL: dlogits[r] = (softmax - onehot) * inv_count (0 rows if ignored); may alias logits.
+ * If dlogits != NULL: dlogits[r] = (softmax - onehot) * inv_count (0 rows if ignored).  In-place use (dlogits == logits, same
+ * ld) is supported: the target logit is read before any store of the row.  A label >= V is treated like ignore_index (it
+ * never indexes the row); callers reject such labels on the host (radvlm_amd.engine does).
  * V may be any size; rows are ld >= ceil8(V) wide, the pad columns are ignored on read and get zero gradient. */
 int rv_cross_entropy(const void* logits, int64_t ld, const int64_t* labels, float* loss_rows, void* dlogits,
                      int64_t ld_d, int rows, int V, float inv_count, void* stream);

@@ -692,12 +692,44 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(GemmParams P) {
 
 }  // namespace
 
+// ---- process-wide launch configuration (the ONLY state this file keeps; one process drives one GPU) ----------
+//   g_tail_split / g_force_kernel : measurement hooks (rv_gemm_select_kernel; RV_GEMM_KERNEL at first use)
+//   g_cus                         : compute units the tile-round heuristics plan for = the device's multiProcessorCount minus the
+//                                   units reserved for concurrently running collectives (rv_gemm_set_cu_budget / RV_GEMM_RESERVED_CUS);
+//                                   queried once per process on first use
+//   per-instantiation `attr` flags: hipFuncSetAttribute(MaxDynamicSharedMemorySize) is issued once per kernel instantiation
+// None of it depends on the arguments of a call; results never depend on it (only which launch shape computes them).
 static int g_tail_split = 1;   // rv_gemm_select_kernel(20) disables the tail split (A/B), (21) enables
 static int g_force_kernel = 0;  // 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel (RV_GEMM_KERNEL or rv_gemm_select_kernel)
+static int g_cus = 0;           // 0 = not yet queried
+static int g_reserved_cus = -1; // -1 = take RV_GEMM_RESERVED_CUS (default 0) at first use
 extern "C" int rv_gemm_select_kernel(int which) {
     if (which >= 20) { g_tail_split = which - 20; return RV_OK; }
     g_force_kernel = which;
     return RV_OK;
+}
+// Number of compute units the GEMM's round / tail-split / split-K heuristics plan for.  total_cus <= 0: ask the device
+// (hipDeviceProp_t::multiProcessorCount of the current device); reserved_cus: units left to other streams (an RCCL all-reduce
+// overlapped with backward occupies a few dozen), subtracted from the total.  Returns the resulting budget.
+extern "C" int rv_gemm_set_cu_budget(int total_cus, int reserved_cus) {
+    if (total_cus <= 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return RV_ERR_LAUNCH;
+        total_cus = prop.multiProcessorCount;
+    }
+    if (reserved_cus < 0) reserved_cus = 0;
+    g_reserved_cus = reserved_cus;
+    g_cus = total_cus - reserved_cus;
+    if (g_cus < 8) g_cus = 8;
+    return g_cus;
+}
+static int cu_budget() {
+    if (g_cus == 0) {
+        const char* e = getenv("RV_GEMM_RESERVED_CUS");
+        rv_gemm_set_cu_budget(0, g_reserved_cus >= 0 ? g_reserved_cus : (e ? atoi(e) : 0));
+    }
+    return g_cus;
 }
 
 template <bool TA, bool TB, int MODE>
@@ -748,32 +780,33 @@ extern "C" int rv_gemm_bf16_ex(const void* A, int64_t lda, const void* B, int64_
     const long tiles256 = (long)((M + BM2 - 1) / BM2) * ((N + BN2 - 1) / BN2);
     const int nt = (K + BK - 1) / BK;
     const int force = g_force_kernel;
+    const int cus = cu_budget();            // 256 on an idle MI355X; fewer when collectives are planned to run beside the GEMMs
     // split-K: few output tiles but a long contraction (LoRA / bias-like gradients): spread K over the idle CUs
     int mode = ext ? 1 : 0;
-    if (!ext && workspace && tiles256 <= 64 && nt >= 16) {
-        int sp = (int)(256 / tiles256);
+    if (!ext && workspace && tiles256 <= cus / 4 && nt >= 16) {
+        int sp = (int)(cus / tiles256);
         if (sp > nt / 4) sp = nt / 4;
         if (sp > 32) sp = 32;
         if (sp >= 2 && (int64_t)sp * M * N * 4 <= workspace_bytes) { mode = 2; P.splits = sp; }
     }
-    // tail split: when the last round of 256 CUs is at most half full, its tiles are cut into 2-4 K-slices so that the
-    // round costs 1/2 - 1/4 of a full one (e.g. 1408 tiles: 6 rounds -> 5.5)
+    // tail split: when the last round of `cus` blocks is at most half full, its tiles are cut into 2-4 K-slices so that the
+    // round costs 1/2 - 1/4 of a full one (e.g. 1408 tiles on 256 CUs: 6 rounds -> 5.5)
     P.n_full = 0;
-    if (mode == 0 && workspace && g_tail_split && tiles256 > 256) {
-        const int rem = (int)(tiles256 % 256);
-        if (rem > 0 && rem <= 128 && nt >= 32) {
-            int sp = 256 / rem;
+    if (mode == 0 && workspace && g_tail_split && tiles256 > cus) {
+        const int rem = (int)(tiles256 % cus);
+        if (rem > 0 && rem <= cus / 2 && nt >= 32) {
+            int sp = cus / rem;
             if (sp > 4) sp = 4;
             if ((int64_t)rem * sp * BM2 * BN2 * 4 <= workspace_bytes) { mode = 3; P.splits = sp; P.n_full = (int)(tiles256 - rem); }
         }
     }
     // the 128x128 kernel only exists for the plain NT form
-    // tile-shape choice for the plain NT form: whole rounds of 256 CUs (256^2 tiles, 1 block/CU) against double-rounds of
-    // 512 blocks (128^2 tiles, 2 blocks/CU, ~15 % less efficient per flop but finer grained); measured crossover on
+    // tile-shape choice for the plain NT form: whole rounds of `cus` blocks (256^2 tiles, 1 block/CU) against double-rounds of
+    // 2 x cus blocks (128^2 tiles, 2 blocks/CU, ~15 % less efficient per flop but finer grained); measured crossover on
     // MI355X (tools/ab_kernel12.py): 292 / 352 tiles -> 128^2 wins by 8-27 %, >= 876 tiles -> 256^2 wins by 3-7 %.
     const long tiles128 = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    const double cost256 = 4.0 * (double)((tiles256 + 255) / 256);
-    const double cost128 = 2.0 * 1.15 * (double)((tiles128 + 511) / 512);
+    const double cost256 = 4.0 * (double)((tiles256 + cus - 1) / cus);
+    const double cost128 = 2.0 * 1.15 * (double)((tiles128 + 2 * cus - 1) / (2 * cus));
     const bool use256 = (trans_a || trans_b || mode) ? true : (force ? (force == 2) : (cost256 <= cost128));
     hipStream_t st = (hipStream_t)stream;
     if (use256) {

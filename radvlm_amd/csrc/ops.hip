@@ -429,7 +429,10 @@ __global__ __launch_bounds__(TPB) void cross_entropy_kernel(const bf16* logits, 
     const int64_t label = labels[row];
     const bf16* lr = logits + row * ld;
     const int nvec = (V + 7) / 8;
-    if (label < 0) {  // ignore_index
+    // The target logit is read BEFORE any dlogits store: the engine calls this kernel in place (dlogits == logits), and other
+    // waves of the block start overwriting the row as soon as they pass the barrier below.
+    const float target = (label >= 0 && label < V) ? bf2f(lr[label]) : 0.f;
+    if (label < 0 || label >= V) {  // ignore_index; labels >= V never index the row (the host side rejects them before launch)
         if (threadIdx.x == 0) loss_rows[row] = 0.f;
         if (dlogits) {
             const float z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(TPB) void cross_entropy_kernel(const bf16* logits, 
 #pragma unroll
     for (int i = 0; i < 4; ++i) gs += (red[i] == -INFINITY) ? 0.f : red[4 + i] * __expf(red[i] - gm);
     const float lse = gm + __logf(gs);
-    if (threadIdx.x == 0) loss_rows[row] = lse - bf2f(lr[label]);
+    if (threadIdx.x == 0) loss_rows[row] = lse - target;
     if (dlogits) {
         for (int i = threadIdx.x; i < nvec; i += TPB) {
             float v[8], o[8];

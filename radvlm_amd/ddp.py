@@ -22,6 +22,7 @@ class FlatGradSync:
         self.min_bucket = min_bucket_elems
         self._lo = self._hi = None
         self.launched = []  # (start, end) of every collective issued since the last finish(); for tests/telemetry
+        self.timing = None  # bench: a list collects (event before, event after) of every finish() on the compute stream
 
     def bucket_done(self, start, end):
         """Elements [start, end) are final. Adjacent ready ranges are coalesced until >= min_bucket_elems."""
@@ -57,10 +58,17 @@ class FlatGradSync:
     def finish(self):
         """Block the compute stream until every bucket is reduced."""
         self._launch()
+        ev = None
+        if self.timing is not None and self.on_gpu:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for w in self.pending:
             w.wait()
         self.pending = []
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
+        if ev is not None:      # elapsed = how long the compute stream sat waiting for the reduced gradients (exposed communication)
+            ev[1].record()
+            self.timing.append(ev)
         out, self.launched = self.launched, []
         return out

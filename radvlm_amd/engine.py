@@ -33,7 +33,8 @@ def _ru(x, m):
 class LlavaEngine:
     def __init__(self, geo, device="cuda", merge_type="flat", image_aspect_ratio="square", image_grid_pinpoints=None,
                  max_len=None, init="portable", seed=0, rms_eps=1e-5, rope_theta=10000.0, process_group=None,
-                 bucket_layers=1, train_vision_tower=False, lora=None, packed="auto", freeze_lm=False):
+                 bucket_layers=1, train_vision_tower=False, lora=None, packed="auto", freeze_lm=False, train_embed_tokens=False,
+                 padding_side="right"):
         self.geo = geo
         # packed (varlen) decoder batches: True / False / "auto" (pack when the samples of a batch differ in length): the decoder
         # then runs on sum(len_b) token rows instead of B * max(len_b) -- no padding rows through GEMMs, norms, CE
@@ -85,7 +86,10 @@ class LlavaEngine:
             from collections import OrderedDict
             full = lm_param_shapes(geo, self.with_newline)
             self.base = FlatParams(lm_param_shapes(geo, False), self.device)
-            self.lm = FlatParams(OrderedDict((k, v) for k, v in full.items() if "mm_projector" in k or k == "model.image_newline"), self.device)
+            # train_embed_tokens: tune_mm_mlp_adapter + mm_use_im_start_end makes the INPUT embeddings trainable as well
+            # (llava_arch.py:577-581: get_input_embeddings requires_grad True, get_output_embeddings False)
+            keep = lambda k: "mm_projector" in k or k == "model.image_newline" or (train_embed_tokens and k == "model.embed_tokens.weight")
+            self.lm = FlatParams(OrderedDict((k, v) for k, v in full.items() if keep(k)), self.device)
             self.vis = FlatParams(vision_param_shapes(geo), self.device)
         elif train_vision_tower:
             # mm_tunable_parts contains mm_vision_tower (train/train.py:1658-1661): the tower joins the trainable flat
@@ -126,44 +130,58 @@ class LlavaEngine:
         self.sync = FlatGradSync(self.grads, process_group) if self.world > 1 else None
         self.ctx = None
         self.grad_accum_started = False
+        self.loss_scale = 1.0
+        assert padding_side in ("right", "left")
+        self.padding_side = padding_side     # config.tokenizer_padding_side (llava_arch.py:520-524)
 
     # ------------------------------------------------------------------ vocabulary
     def resize_token_embeddings(self, new_vocab):
         """resize_token_embeddings + the mean initialisation of initialize_vision_tokenizer (llava_arch.py:563-575): embed_tokens and
-        lm_head grow to `new_vocab` rows, the added rows start as the mean of the existing ones.  The flat parameter / gradient
-        buffers are rebuilt (every other tensor is copied bit for bit) and the optimizer state restarts."""
+        lm_head grow to `new_vocab` rows, the added rows start as the mean of the existing ones.  Every store that holds one of the
+        two tables (the trainable buffer, or the frozen base of LoRA / projector-only runs) is rebuilt with every other tensor copied
+        bit for bit; the optimizer state restarts."""
         old_v = self.vocab
         if new_vocab == old_v:
             return
-        assert new_vocab > old_v and not self.lora, "growing a full (non-LoRA) model only"
+        assert new_vocab > old_v, "the vocabulary only grows"
         import copy
         from collections import OrderedDict
+        tables = ("model.embed_tokens.weight", "lm_head.weight")
         phys = _ru(int(new_vocab), 8)        # table rows: a multiple of 8 (GEMM / CE vector width); rows >= new_vocab stay exactly zero
         geo = copy.deepcopy(self.geo)
         geo["lm"]["vocab"] = phys
-        shapes = OrderedDict(vision_param_shapes(geo)) if self.train_tower else OrderedDict()
-        shapes.update(lm_param_shapes(geo, self.with_newline))
-        new = FlatParams(shapes, self.device)
-        for name in self.lm.names():
-            src, dst = self.lm.view(name), new.view(name)
-            if name in ("model.embed_tokens.weight", "lm_head.weight"):
-                dst[:old_v].copy_(src[:old_v])
-                dst[old_v:new_vocab].copy_(src[:old_v].float().mean(dim=0, keepdim=True).to(BF16).expand(new_vocab - old_v, -1))
-            else:
-                dst.copy_(src)
-        self.vocab = int(new_vocab)
+
+        def grow(store):
+            if not any(t in store.offsets for t in tables):
+                return store
+            shapes = OrderedDict((n, ((phys, shp[1]) if n in tables else shp)) for n, shp in store.shapes.items())
+            new = FlatParams(shapes, self.device)
+            for name in store.names():
+                src, dst = store.view(name), new.view(name)
+                if name in tables:
+                    dst[:old_v].copy_(src[:old_v])
+                    dst[old_v:new_vocab].copy_(src[:old_v].float().mean(dim=0, keepdim=True).to(BF16).expand(new_vocab - old_v, -1))
+                else:
+                    dst.copy_(src)
+            return new
+
         tower_shared = self.vis is self.lm
+        new_lm = grow(self.lm)
+        if self.base is not None:
+            self.base = grow(self.base)
+        self.vocab = int(new_vocab)
         self.geo, self.l, self.v = geo, geo["lm"], geo["vision"]
-        self.lm = new
-        if tower_shared:
-            self.vis = new
-        self.grads = new.like(BF16)
-        self.master = self.m = self.vv = None
-        self.opt_step = 0
-        self.grad_accum_started = False
-        if self.world > 1:
-            from .ddp import FlatGradSync
-            self.sync = FlatGradSync(self.grads, self.pg)
+        if new_lm is not self.lm:
+            self.lm = new_lm
+            if tower_shared:
+                self.vis = new_lm
+            self.grads = new_lm.like(BF16)
+            self.master = self.m = self.vv = None
+            self.opt_step = 0
+            self.grad_accum_started = False
+            if self.world > 1:
+                from .ddp import FlatGradSync
+                self.sync = FlatGradSync(self.grads, self.pg)
         self.weights_changed()
 
     # ------------------------------------------------------------------ weights
@@ -431,7 +449,7 @@ class LlavaEngine:
         ids = np.asarray(input_ids)
         am = np.asarray(attention_mask).astype(bool) if attention_mask is not None else np.ones_like(ids, dtype=bool)
         lab = np.asarray(labels) if labels is not None else np.full_like(ids, -100)
-        plan = build_splice_plan(ids, am, lab, rows, n_proj + n_extra, self.max_len)
+        plan = build_splice_plan(ids, am, lab, rows, n_proj + n_extra, self.max_len, self.padding_side)
         plan["n_feat_rows"] = n_proj + n_extra
         plan["n_proj_rows"] = n_proj
         plan["n_extra_rows"] = n_extra
@@ -455,8 +473,10 @@ class LlavaEngine:
                 adj_pos=(n_proj + order // 4).astype(np.int32), adj_w=w[order], adj_out=usrc.astype(np.int32))
         return plan
 
-    def forward(self, input_ids, attention_mask, labels, images, image_sizes=None, want_logits=False, loss_scale=1.0):
-        """One training forward. Returns loss (fp32 device tensor [1]); keeps the context for backward()."""
+    def forward(self, input_ids, attention_mask, labels, images, image_sizes=None, want_logits=False, loss_scale=None):
+        """One training forward. Returns loss (fp32 device tensor [1], never scaled); keeps the context for backward().
+        loss_scale multiplies the GRADIENTS only (default: self.loss_scale; a trainer sets 1 / gradient_accumulation_steps, which is
+        what HF Trainer.training_step back-propagates, HF:trainer.py training_step `loss / gradient_accumulation_steps`)."""
         dev = self.device
         l = self.l
         d, F, H, V, L = l["d"], l["ffn"], l["heads"], l["vocab"], l["layers"]
@@ -472,7 +492,18 @@ class LlavaEngine:
         S = plan["S"]
         s_pad = _ru(S, 64)
         lens_np = plan["lens"]
-        packed = bool(self.packed) if self.packed != "auto" else bool((lens_np != S).any())
+        ragged = bool((lens_np != S).any())
+        packed = bool(self.packed) if self.packed != "auto" else ragged
+        if self.padding_side == "left" and ragged:
+            # left padding (llava_arch.py:520-524): the reference discards the spliced position_ids in training (:534-545), so
+            # every row keeps positions arange(S) and a short sample starts at position S - len.  That is exactly the packed
+            # layout with explicit positions = padded column index: valid tokens only, nothing computed for the pad rows.
+            packed = True
+            first = S - lens_np
+            bad = [b for b in range(len(lens_np)) if 0 < lens_np[b] < S and plan["labels"][b, first[b]] != -100]
+            if bad:
+                raise ValueError(f"left padding: sample {bad[0]} has a label on its first token; the reference's loss would then read the "
+                                 "logits of a padding row (shifted CE), which is not defined here")
         cu = pos = valid_idx = None
         if packed:
             valid = plan["attention_mask"].reshape(-1)
@@ -524,6 +555,8 @@ class LlavaEngine:
         hN, rstdN = ops.rmsnorm_fwd(x, self.W("model.norm.weight"), self.eps)
         logits = ops.gemm_nt(hN, self.W("lm_head.weight"))
         tgt = shifted_labels(plan["labels"])
+        if tgt.size and int(tgt.max()) >= self.vocab:     # torch's cross_entropy raises on an out-of-range target too
+            raise IndexError(f"label {int(tgt.max())} is out of range for a vocabulary of {self.vocab}")
         count = int((tgt != -100).sum())
         inv = (1.0 / count) if count > 0 else float("nan")
         tgt = tgt.reshape(-1)
@@ -531,14 +564,18 @@ class LlavaEngine:
             tgt = tgt[valid_idx]
         tgt_t = torch.from_numpy(tgt).to(dev, non_blocking=True)
         logits_out = None
-        if want_logits and packed:      # callers see the reference's padded [B, S, V] shape (padding rows zero)
-            logits_out = torch.zeros(B * S, V, dtype=torch.float32, device=dev)
-            logits_out[torch.from_numpy(valid_idx).to(dev)] = ops.to_f32(logits)
+        if want_logits:
+            # callers get the reference's fp32 [B, S, V] (llava_llama.py:69-120 -> logits.float()): the lm_head GEMM once more with
+            # fp32 output, i.e. the accumulators without the bf16 store the training path's loss reads (eval / tests only)
+            lf = ops.gemm_nt(hN, self.W("lm_head.weight"), out_dtype=torch.float32)
+            if packed:          # padded shape, padding rows zero
+                logits_out = torch.zeros(B * S, V, dtype=torch.float32, device=dev)
+                logits_out[torch.from_numpy(valid_idx).to(dev)] = lf
+            else:
+                logits_out = lf
             logits_out = logits_out.view(B, S, V)[..., :self.vocab]
-        elif want_logits:
-            logits_out = ops.to_f32(logits).view(B, S, V)[..., :self.vocab]
         # CE writes dlogits (scaled by loss_scale/count/world) over the logits buffer
-        gscale = loss_scale / self.world
+        gscale = (self.loss_scale if loss_scale is None else loss_scale) / self.world
         loss, _ = self._cross_entropy(logits, tgt_t, self.vocab, inv, gscale)   # V = table rows (pad rows included), CE sees the logical vocabulary
         ctx.update(B=B, S=S, M=M, s_pad=s_pad, lens=lens, cu=cu, pos=pos, layers=layers, x_last=x, rstdN=rstdN, hN=hN, dlogits=logits,
                    table_rows=table.shape[0], count=count)
@@ -704,8 +741,9 @@ class LlavaEngine:
                                      torch.from_numpy(npos).to(dev), torch.zeros(1, dtype=torch.int32, device=dev), tmp)
                 gn.add_(tmp) if acc else gn.copy_(tmp)
         # embedding rows: segment sums by token id (no atomics)
-        ge = g("model.embed_tokens.weight") if not frozen_lm else None
-        if frozen_lm:
+        train_embed = "model.embed_tokens.weight" in self.lm.offsets     # full fine-tune, or the pretraining stage with extra tokens
+        ge = g("model.embed_tokens.weight") if train_embed else None
+        if not train_embed:
             pass
         elif acc:
             tmp = torch.zeros_like(ge)
@@ -717,7 +755,7 @@ class LlavaEngine:
             ops.segment_sum_rows(dx, torch.from_numpy(plan["tok_off"]).to(dev), torch.from_numpy(plan["tok_pos"]).to(dev),
                                  torch.from_numpy(plan["tok_ids"]).to(dev), ge)
         last = "model.image_newline" if self.with_newline else "model.mm_projector.2.bias"
-        self._bucket_done("model.mm_projector.0.weight" if frozen_lm else "model.embed_tokens.weight", last)
+        self._bucket_done("model.embed_tokens.weight" if train_embed else "model.mm_projector.0.weight", last)
         if self.train_tower:
             if self.has_cls:
                 n_img = c["v_n"]

@@ -145,7 +145,9 @@ class LlavaLlamaForCausalLM:
                                   max_len=config.tokenizer_model_max_length, init=init, seed=seed, rms_eps=config.rms_norm_eps,
                                   rope_theta=config.rope_theta, process_group=process_group,
                                   train_vision_tower=getattr(config, "unfreeze_mm_vision_tower", False),
-                                  lora=getattr(config, "lora", None), freeze_lm=getattr(config, "freeze_lm", False))
+                                  lora=getattr(config, "lora", None), freeze_lm=getattr(config, "freeze_lm", False),
+                                  train_embed_tokens=getattr(config, "train_embed_tokens", False),
+                                  padding_side=getattr(config, "tokenizer_padding_side", "right"))
         self.model = self.model_class(self.engine, config)
         self.training = True
         # a leaf that makes loss require grad so that `.backward()` reaches the engine
@@ -182,18 +184,37 @@ class LlavaLlamaForCausalLM:
 
     def initialize_vision_tokenizer(self, model_args, tokenizer):
         """llava_arch.py:557-597: optional <im_patch> / <im_start>, <im_end> tokens are added to the tokenizer and the embedding
-        tables grow by as many rows, initialised to the mean of the existing rows (full fine-tuning; the projector-only variants
-        that flip requires_grad on the embeddings, :577-581 / :593-597, belong to the pretraining stage and are not built)."""
+        tables grow by as many rows, initialised to the mean of the existing rows (:563-575).  In the pretraining stage
+        (tune_mm_mlp_adapter) the INPUT embeddings then train with the projector while lm_head stays frozen (:577-581: build the
+        model with config.train_embed_tokens=True, as train() does), and with pretrain_mm_mlp_adapter the two new embedding rows
+        are restored from that file (:583-592)."""
         from ..constants import DEFAULT_IM_END_TOKEN, DEFAULT_IM_START_TOKEN, DEFAULT_IMAGE_PATCH_TOKEN
+        e = self.engine
         if getattr(model_args, "mm_use_im_patch_token", False):
             tokenizer.add_tokens([DEFAULT_IMAGE_PATCH_TOKEN], special_tokens=True)
-            self.engine.resize_token_embeddings(max(len(tokenizer), self.engine.l["vocab"]))
+            e.resize_token_embeddings(max(len(tokenizer), e.vocab))
         if getattr(model_args, "mm_use_im_start_end", False):
-            if getattr(model_args, "tune_mm_mlp_adapter", False):
-                raise NotImplementedError("tune_mm_mlp_adapter with mm_use_im_start_end (pretraining stage)")
-            tokenizer.add_tokens([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN], special_tokens=True)
-            self.engine.resize_token_embeddings(max(len(tokenizer), self.engine.l["vocab"]))
-            self.config.vocab_size = self.engine.l["vocab"]
+            num_new = tokenizer.add_tokens([DEFAULT_IM_START_TOKEN, DEFAULT_IM_END_TOKEN], special_tokens=True)
+            e.resize_token_embeddings(max(len(tokenizer), e.vocab))
+            if getattr(model_args, "tune_mm_mlp_adapter", False) and "model.embed_tokens.weight" not in e.lm.offsets:
+                raise ValueError("tune_mm_mlp_adapter + mm_use_im_start_end trains the input embeddings (llava_arch.py:577-581): "
+                                 "build the model with config.train_embed_tokens=True")
+            p = getattr(model_args, "pretrain_mm_mlp_adapter", None)
+            if p:
+                w = torch.load(p, map_location="cpu", weights_only=True)["model.embed_tokens.weight"]
+                assert num_new == 2
+                emb = e.W("model.embed_tokens.weight")
+                if w.shape[0] in (e.vocab, emb.shape[0]) and w.shape[1] == emb.shape[1]:
+                    emb[e.vocab - num_new:e.vocab].copy_(w[e.vocab - num_new:e.vocab].to(emb.dtype))
+                elif w.shape[0] == num_new:
+                    emb[e.vocab - num_new:e.vocab].copy_(w.to(emb.dtype))
+                else:
+                    raise ValueError(f"Unexpected embed_tokens_weight shape. Pretrained: {tuple(w.shape)}. Current: {(e.vocab, emb.shape[1])}. "
+                                     f"Numer of new tokens: {num_new}.")
+                if e.master is not None:
+                    from ... import ops
+                    e.master.copy_(ops.to_f32(e.lm.flat))
+        self.config.vocab_size = e.vocab
         self.config.mm_use_im_start_end = bool(getattr(model_args, "mm_use_im_start_end", False))
 
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None, labels=None,
@@ -217,13 +238,62 @@ class LlavaLlamaForCausalLM:
 
     __call__ = forward
 
-    def save_pretrained(self, out_dir):
-        from safetensors.torch import save_file
+    def save_config(self, out_dir):
+        """config.json in HF's key vocabulary (what model.config.save_pretrained leaves next to the weights), plus the tower
+        geometry under 'mm_vision_geometry' so that the directory is loadable as --model_name_or_path on its own."""
+        import json
         os.makedirs(out_dir, exist_ok=True)
+        c, l = self.config, self.engine.l
+        d = {"model_type": c.model_type, "architectures": [type(self).__name__], "hidden_size": l["d"], "intermediate_size": l["ffn"],
+             "num_hidden_layers": l["layers"], "num_attention_heads": l["heads"], "num_key_value_heads": l.get("kv_heads", l["heads"]),
+             "vocab_size": self.engine.vocab, "rms_norm_eps": self.engine.eps, "rope_theta": self.engine.theta, "torch_dtype": "bfloat16",
+             "use_cache": False, "mm_vision_geometry": dict(self.engine.v)}
+        for k, v in vars(c).items():
+            if k.startswith(("mm_", "image_", "tokenizer_")) and isinstance(v, (str, int, float, bool, list, type(None))):
+                d[k] = v
+        with open(os.path.join(out_dir, "config.json"), "w") as f:
+            json.dump(d, f, indent=2)
+
+    def save_pretrained(self, out_dir):
+        """Weights in the reference's formats.  Full fine-tune: model.safetensors under the reference state-dict names.  LoRA
+        (train/train.py:1708-1717): what peft's save_pretrained(state_dict=get_peft_state_maybe_zero_3(...)) leaves --
+        adapter_model.bin (torch.save; keys base_model.model.<module>.lora_{A,B}.weight, adapter name stripped) and
+        adapter_config.json -- plus non_lora_trainables.bin (torch.save of the trainable non-LoRA tensors under their
+        base_model.model.* names).  peft itself is not installed here: the two adapter files restate its published layout."""
+        from safetensors.torch import save_file
+        self.save_config(out_dir)
+        cpu = lambda d: {k: v.detach().clone().contiguous().cpu() for k, v in d.items()}
         if self.engine.lora:
-            adapters, others = self.engine.lora_state_dict()   # reference: adapter weights + non_lora_trainables (train.py:1708-1717)
-            save_file({k: v.detach().clone().contiguous().cpu() for k, v in adapters.items()}, os.path.join(out_dir, "adapter_model.safetensors"))
-            save_file({k: v.detach().clone().contiguous().cpu() for k, v in others.items()}, os.path.join(out_dir, "non_lora_trainables.safetensors"))
+            import json
+            adapters, others = self.engine.lora_state_dict()
+            torch.save(cpu({k.replace(".default.weight", ".weight"): v for k, v in adapters.items()}), os.path.join(out_dir, "adapter_model.bin"))
+            torch.save(cpu({"base_model.model." + k: v for k, v in others.items()}), os.path.join(out_dir, "non_lora_trainables.bin"))
+            lo = self.engine.lora
+            with open(os.path.join(out_dir, "adapter_config.json"), "w") as f:
+                json.dump({"peft_type": "LORA", "task_type": "CAUSAL_LM", "base_model_name_or_path": getattr(self.config, "_name_or_path", None),
+                           "r": lo["r"], "lora_alpha": lo.get("alpha", 16), "lora_dropout": lo.get("dropout", 0.0), "bias": "none",
+                           "target_modules": ["q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj"],
+                           "fan_in_fan_out": False, "inference_mode": True, "init_lora_weights": True, "modules_to_save": None,
+                           "layers_to_transform": None, "layers_pattern": None, "revision": None}, f, indent=2)
             return
-        sd = {k: v.detach().clone().contiguous().cpu() for k, v in self.engine.state_dict().items()}
-        save_file(sd, os.path.join(out_dir, "model.safetensors"))
+        save_file(cpu(self.engine.state_dict()), os.path.join(out_dir, "model.safetensors"))
+
+    def load_adapter(self, path):
+        """Inverse of the LoRA branch of save_pretrained (resume / continued training): adapter_model.bin + non_lora_trainables.bin."""
+        e = self.engine
+        assert e.lora, "load_adapter needs a LoRA engine"
+        strip = lambda k: k[len("base_model.model."):] if k.startswith("base_model.model.") else k
+        sd = {}
+        for name in ("adapter_model.bin", "non_lora_trainables.bin"):
+            f = os.path.join(path, name)
+            if os.path.exists(f):
+                sd.update({strip(k).replace(".default.weight", ".weight"): v for k, v in torch.load(f, map_location="cpu", weights_only=True).items()})
+        if not sd:
+            raise FileNotFoundError(f"no adapter_model.bin / non_lora_trainables.bin under {path}")
+        from ...params import load_named
+        missing, unexpected = load_named(e.lm, sd)
+        if missing or unexpected:
+            raise KeyError(f"adapter checkpoint does not match the model: missing={missing[:4]} unexpected={unexpected[:4]}")
+        if e.master is not None:
+            from ... import ops
+            e.master.copy_(ops.to_f32(e.lm.flat))

@@ -143,11 +143,57 @@ def shard_for_rank(indices, per_device_batch, world_size, rank):
 
 
 def cosine_lr(step, total_steps, base_lr, warmup_steps):
-    """HF 'cosine' schedule with linear warmup (lr_scheduler_type cosine, warmup_ratio 0.03 in the reference script)."""
+    """HF 'cosine' schedule with linear warmup (get_cosine_schedule_with_warmup, num_cycles 0.5): the multiplier at scheduler
+    step `step` (0-based: the k-th optimizer update of a run uses step = k - 1, see lr_at)."""
     if step < warmup_steps:
         return base_lr * step / max(1, warmup_steps)
     p = (step - warmup_steps) / max(1, total_steps - warmup_steps)
     return base_lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * p)))
+
+
+def warmup_steps_for(args, total_steps):
+    """TrainingArguments.get_warmup_steps: warmup_steps if > 0 else ceil(total * warmup_ratio)."""
+    ws = int(getattr(args, "warmup_steps", 0) or 0)
+    return ws if ws > 0 else math.ceil(total_steps * float(getattr(args, "warmup_ratio", 0.0) or 0.0))
+
+
+def lr_at(update, total_steps, base_lr, warmup_steps, kind="cosine"):
+    """Learning rate of the `update`-th optimizer step (1-based).  HF Trainer steps the scheduler AFTER the optimizer, so update k
+    runs at lambda(k - 1): the first update of a warmed-up run has lr 0 and the last one lr > 0 (finetune_radio_7b.sh:
+    --lr_scheduler_type cosine --warmup_ratio 0.03)."""
+    s = update - 1
+    if kind == "cosine":
+        return cosine_lr(s, total_steps, base_lr, warmup_steps)
+    if s < warmup_steps:
+        return base_lr * s / max(1, warmup_steps)
+    if kind == "linear":
+        return base_lr * max(0.0, (total_steps - s) / max(1, total_steps - warmup_steps))
+    if kind in ("constant", "constant_with_warmup"):
+        return base_lr
+    raise ValueError(f"lr_scheduler_type {kind!r}: cosine, linear, constant and constant_with_warmup are built")
+
+
+def epoch_index_batches(n, sampler, seed, per_device_batch, world, rank, accum):
+    """The stream of per-rank micro-batches (lists of dataset indices), epoch after epoch, without end.
+
+    Every epoch draws a fresh order -- `iter(sampler)` on a sampler whose generator was seeded once (what re-iterating the
+    DataLoader does in HF Trainer), or a seeded permutation without a sampler -- and is consumed whole: the r-th
+    `per_device_batch` slice of every world batch belongs to rank r (accelerate's batch sharding of the grouped order,
+    llava_trainer.py:129-149), an incomplete last world batch and the micro-batches that do not fill a last optimizer step
+    are dropped.  Returns (generator, optimizer steps per epoch)."""
+    wb = per_device_batch * world
+    steps_per_epoch = (n // wb) // accum
+    if steps_per_epoch < 1:
+        raise ValueError(f"{n} samples do not fill one optimizer step of {wb} x {accum}")
+    g = torch.Generator().manual_seed(seed)
+
+    def gen():
+        while True:
+            order = list(iter(sampler)) if sampler is not None else torch.randperm(n, generator=g).tolist()
+            mine = shard_for_rank(order, per_device_batch, world, rank)
+            for j in range(steps_per_epoch * accum):
+                yield mine[j * per_device_batch:(j + 1) * per_device_batch]
+    return gen(), steps_per_epoch
 
 
 class BatchPrefetcher:
@@ -251,26 +297,23 @@ class LLaVATrainer:
         a = self.args
         eng = self.model.engine
         world, rank = getattr(a, "world_size", 1), getattr(a, "process_index", 0)
-        sampler = self._get_train_sampler()
-        n = len(self.train_dataset)
-        order = list(iter(sampler)) if sampler is not None else torch.randperm(n, generator=torch.Generator().manual_seed(getattr(a, "seed", 42))).tolist()
-        mine = shard_for_rank(order, a.per_device_train_batch_size, world, rank) if world > 1 else order
-        bs, accum = a.per_device_train_batch_size, getattr(a, "gradient_accumulation_steps", 1)
-        steps_per_epoch = len(mine) // (bs * accum)
-        total = int(getattr(a, "max_steps", -1)) if getattr(a, "max_steps", -1) > 0 else int(steps_per_epoch * a.num_train_epochs)
-        warm = int(getattr(a, "warmup_steps", 0) or total * getattr(a, "warmup_ratio", 0.0))
-        def index_batches():
-            pos = 0
-            for _ in range(total * accum):
-                yield mine[pos:pos + bs]
-                pos = (pos + bs) % max(1, len(mine) - bs + 1)
+        bs, accum = a.per_device_train_batch_size, max(1, int(getattr(a, "gradient_accumulation_steps", 1) or 1))
+        it, steps_per_epoch = epoch_index_batches(len(self.train_dataset), self._get_train_sampler(), getattr(a, "seed", 42), bs, world, rank, accum)
+        max_steps = int(getattr(a, "max_steps", -1) or -1)
+        total = max_steps if max_steps > 0 else math.ceil(steps_per_epoch * float(a.num_train_epochs))
+        warm = warmup_steps_for(a, total)
+        kind = getattr(a, "lr_scheduler_type", "cosine") or "cosine"
+        kind = getattr(kind, "value", kind)
 
         start = self._maybe_resume(resume_from_checkpoint)
-        it = index_batches()
-        for _ in range(start * accum):       # a resumed run continues the same sample stream
+        for _ in range(start * accum):       # a resumed run continues the same sample stream (epoch orders are regenerated from the seed)
             next(it)
-        loader = BatchPrefetcher(self.train_dataset, self.data_collator, it, num_workers=int(getattr(a, "dataloader_num_workers", 0) or 0))
+        loader = BatchPrefetcher(self.train_dataset, self.data_collator, (next(it) for _ in range((total - start) * accum)),
+                                 num_workers=int(getattr(a, "dataloader_num_workers", 0) or 0))
         save_steps = int(getattr(a, "save_steps", 0) or 0)
+        # HF Trainer back-propagates loss / gradient_accumulation_steps for every micro-batch (training_step), so the accumulated
+        # gradient is the MEAN over the micro-batches: same pre-clip norm, same effect of max_grad_norm as one large batch
+        eng.loss_scale = 1.0 / accum
         try:
             for step in range(start + 1, total + 1):
                 t0 = time.perf_counter()
@@ -284,44 +327,64 @@ class LLaVATrainer:
                     out = self.model(**batch)
                     out.loss.backward()
                     losses.append(out.loss)
-                lr = cosine_lr(step, total, a.learning_rate, warm)
+                lr = lr_at(step, total, a.learning_rate, warm, kind)
+                scale = lr / a.learning_rate if a.learning_rate else 0.0      # the per-module rates follow the same schedule
+                plr, vlr = getattr(a, "mm_projector_lr", None), getattr(a, "mm_vision_tower_lr", None)
                 eng.optimizer_step(lr=lr, weight_decay=a.weight_decay, betas=(getattr(a, "adam_beta1", 0.9), getattr(a, "adam_beta2", 0.999)),
                                    eps=getattr(a, "adam_epsilon", 1e-8), max_grad_norm=getattr(a, "max_grad_norm", 1.0),
-                                   mm_projector_lr=getattr(a, "mm_projector_lr", None),
-                                   mm_vision_tower_lr=getattr(a, "mm_vision_tower_lr", None))
+                                   mm_projector_lr=None if plr is None else plr * scale,
+                                   mm_vision_tower_lr=None if vlr is None else vlr * scale)
                 self.state["global_step"] = step
                 if step % max(1, getattr(a, "logging_steps", 1)) == 0:
                     rec = {"step": step, "loss": float(sum(float(l) for l in losses) / len(losses)), "learning_rate": lr,
-                           "step_time_s": time.perf_counter() - t0, "data_wait_s": t_data}
+                           "grad_norm": float(eng.last_grad_norm) if eng.last_grad_norm is not None else None,
+                           "epoch": step / steps_per_epoch, "step_time_s": time.perf_counter() - t0, "data_wait_s": t_data}
                     self.state["log_history"].append(rec)
                     if rank == 0:
                         print(rec, flush=True)
                 if save_steps and step % save_steps == 0 and getattr(a, "output_dir", None):
                     self.save_checkpoint(os.path.join(a.output_dir, f"checkpoint-{step}"), rank)
         finally:
+            eng.loss_scale = 1.0
             loader.close()
         return self.state
 
     # ------------------------------------------------------------------ checkpoints
+    def _adapter_only(self):
+        """tune_mm_mlp_adapter, or mm_tunable_parts naming only the projector (llava_trainer.py:436-438)."""
+        a = self.args
+        parts = (getattr(a, "mm_tunable_parts", None) or "").split(",")
+        return bool(getattr(a, "tune_mm_mlp_adapter", False)) or (len(parts) == 1 and parts[0].strip() in ("mm_mlp_adapter", "mm_vision_resampler"))
+
     def save_checkpoint(self, path, rank=0):
         """checkpoint-N directory with what a resumed run needs (train.py:1699-1702 auto-resume looks for checkpoint-*):
-        weights in the reference's state-dict names (safetensors), the adapter-only file of projector-only runs
-        (llava_trainer.py:435-457 writes mm_projector.bin with the keys matched by 'mm_projector'), fp32 master + AdamW moments
-        and the trainer state.  Written by rank 0 only (replicas are identical under data parallelism)."""
+          * full fine-tune: model.safetensors under the reference's state-dict names;
+          * projector-only runs (llava_trainer.py:435-457): mm_projector.bin = torch.save of the tensors whose names match
+            'mm_projector' (+ 'embed_tokens' with use_im_start_end), and NO full model;
+          * LoRA runs: adapter_model.bin + adapter_config.json + non_lora_trainables.bin (the layout of train.py:1708-1717);
+          * always: fp32 master + AdamW moments of the trainable buffer and the trainer state.
+        Written by rank 0 only (replicas are identical under data parallelism)."""
         if rank != 0:
             return
         import json
         from safetensors.torch import save_file
         eng = self.model.engine
         os.makedirs(path, exist_ok=True)
-        self.model.save_pretrained(path)
-        proj = {k: v.detach().clone().cpu() for k, v in eng.state_dict().items() if "mm_projector" in k}
-        torch.save(proj, os.path.join(path, "mm_projector.bin"))
+        if self._adapter_only() and not eng.lora:
+            keys = ["mm_projector", "vision_resampler"] + (["embed_tokens", "embed_in"] if getattr(self.args, "use_im_start_end", False) else [])
+            sd = {k: v.detach().clone().cpu() for k, v in eng.state_dict().items() if any(m in k for m in keys)}
+            torch.save(sd, os.path.join(path, "mm_projector.bin"))
+        else:
+            self.model.save_pretrained(path)
+            if not eng.lora:
+                proj = {k: v.detach().clone().cpu() for k, v in eng.state_dict().items() if "mm_projector" in k}
+                torch.save(proj, os.path.join(path, "mm_projector.bin"))
         if eng.master is not None:
             save_file({"master": eng.master.detach().cpu(), "exp_avg": eng.m.detach().cpu(), "exp_avg_sq": eng.vv.detach().cpu()},
                       os.path.join(path, "optimizer.safetensors"))
         with open(os.path.join(path, "trainer_state.json"), "w") as f:
-            json.dump({"global_step": self.state["global_step"], "opt_step": eng.opt_step, "log_history": self.state["log_history"]}, f)
+            json.dump({"global_step": self.state["global_step"], "opt_step": eng.opt_step, "lora_step": eng.lora_step,
+                       "log_history": self.state["log_history"]}, f)
 
     def _maybe_resume(self, resume_from_checkpoint):
         """True -> newest checkpoint-* under output_dir (the reference's auto-resume, train.py:1699-1702); str -> that directory."""
@@ -336,10 +399,12 @@ class LLaVATrainer:
         import json
         from safetensors.torch import load_file
         eng = self.model.engine
-        name = "model.safetensors" if not eng.lora else None
-        if name is None:
-            raise NotImplementedError("resume of LoRA runs")
-        eng.load_state_dict(load_file(os.path.join(path, name)))
+        if eng.lora:
+            self.model.load_adapter(path)
+        elif os.path.exists(os.path.join(path, "model.safetensors")):
+            eng.load_state_dict(load_file(os.path.join(path, "model.safetensors")))
+        else:       # projector-only checkpoint: the frozen parts are those the run started from
+            eng.load_state_dict(torch.load(os.path.join(path, "mm_projector.bin"), map_location="cpu", weights_only=True))
         opt = os.path.join(path, "optimizer.safetensors")
         if os.path.exists(opt):
             eng.init_optimizer()
@@ -348,6 +413,7 @@ class LLaVATrainer:
         with open(os.path.join(path, "trainer_state.json")) as f:
             ts = json.load(f)
         eng.opt_step = ts["opt_step"]
+        eng.lora_step = ts.get("lora_step", eng.lora_step)      # the dropout masks of a resumed LoRA run continue their counter
         self.state["global_step"] = ts["global_step"]
         self.state["log_history"] = ts["log_history"]
         return ts["global_step"]

@@ -127,7 +127,7 @@ class TrainingArguments:
     max_grad_norm: float = 1.0
     warmup_ratio: float = 0.03
     warmup_steps: int = 0
-    lr_scheduler_type: str = "cosine"
+    lr_scheduler_type: str = "linear"    # HF TrainingArguments default; finetune_radio_7b.sh passes cosine
     logging_steps: int = 1
     save_strategy: str = "steps"
     save_steps: int = 500
@@ -489,6 +489,47 @@ def tunable_parts(model_args):
     return parts
 
 
+def resolve_model_sources(model_args, verbose=False):
+    """Where the weights come from and which geometry they imply (host-only; no device is touched).
+
+    get_model -> from_pretrained (train/train.py:1358-1427) and CLIPVisionTower.load_model (clip_encoder.py:35-44): the LM and the
+    tower start from SAVED weights.  There is no network here, so --model_name_or_path and --vision_tower must be local HF-format
+    directories (config.json + safetensors / bin shards); anything else raises.  The build-specific --geometry NAME switch instead
+    selects a named geometry with RANDOM weights (benchmarks, smoke runs) and loads nothing.
+    Returns (geometry, lm_dir, tower_dir, is_qwen, true_vocab); true_vocab != geometry vocab when the checkpoint's tables have a row
+    count that is not a multiple of 8 (extra tokens were added): the engine is built at the multiple below and then grown."""
+    from ...config import GEOMETRIES
+    mname = (model_args.model_name_or_path or "").lower()
+    # model-class routing of get_model (train/train.py:1366-1436): 'qwen' in the name -> LlavaQwenForCausalLM, else Llama
+    is_qwen = "qwen" in mname or (model_args.geometry or "").find("qwen") >= 0
+    lm_dir = tower_dir = None
+    if model_args.geometry:
+        geometry = GEOMETRIES[model_args.geometry]
+        if verbose:
+            print(f"[radvlm_amd] --geometry {model_args.geometry}: random-init weights, no checkpoint is loaded", flush=True)
+    else:
+        from ...checkpoint_io import lm_geometry_from_config, read_config, vision_geometry_from_config
+        lm_dir = model_args.model_name_or_path
+        if not (lm_dir and os.path.isdir(lm_dir)):
+            raise FileNotFoundError(f"--model_name_or_path {lm_dir!r} is not a local checkpoint directory (nothing is downloaded; "
+                                    "pass --geometry NAME for a random-init run)")
+        lm_cfg = read_config(lm_dir)
+        is_qwen = is_qwen or "qwen" in (lm_cfg.get("model_type") or "").lower()
+        tower_dir = model_args.vision_tower or lm_cfg.get("mm_vision_tower")
+        if "mm_vision_geometry" in lm_cfg:            # a checkpoint written by this package carries its tower inside
+            vgeo = dict(lm_cfg["mm_vision_geometry"])
+            tower_dir = tower_dir if (tower_dir and os.path.isdir(tower_dir)) else None
+        else:
+            if not (tower_dir and os.path.isdir(tower_dir)):
+                raise FileNotFoundError(f"--vision_tower {tower_dir!r} is not a local checkpoint directory (nothing is downloaded)")
+            vgeo = vision_geometry_from_config(read_config(tower_dir))
+        geometry = {"vision": vgeo, "lm": lm_geometry_from_config(lm_cfg)}
+    true_vocab = geometry["lm"]["vocab"]
+    if true_vocab % 8:
+        geometry = {"vision": geometry["vision"], "lm": dict(geometry["lm"], vocab=true_vocab // 8 * 8)}
+    return geometry, lm_dir, tower_dir, is_qwen, true_vocab
+
+
 def train(attn_implementation=None, argv=None, tokenizer=None):
     from ..model import LlavaConfig, LlavaLlamaForCausalLM, LlavaQwenConfig, LlavaQwenForCausalLM
     from ..mm_utils import SigLipImageProcessor
@@ -510,16 +551,20 @@ def train(attn_implementation=None, argv=None, tokenizer=None):
         if training_args.lora_bias != "none" or "mm_vision_tower" in parts:
             raise NotImplementedError("lora_bias != 'none' / LoRA together with a tunable vision tower")
         lora = dict(r=training_args.lora_r, alpha=training_args.lora_alpha, dropout=training_args.lora_dropout)
-    mname = (model_args.model_name_or_path or "").lower()
-    # model-class routing of get_model (train/train.py:1366-1436): 'qwen' in the name -> LlavaQwenForCausalLM, else Llama
-    is_qwen = "qwen" in mname or (model_args.geometry or "").find("qwen") >= 0
-    name = model_args.geometry or ("llava_ov_qwen2_7b" if is_qwen else ("llava15_13b" if "13b" in mname else "llava15_7b"))
+    geometry, lm_dir, tower_dir, is_qwen, true_vocab = resolve_model_sources(model_args, verbose=rank == 0)
     Config, Model = (LlavaQwenConfig, LlavaQwenForCausalLM) if is_qwen else (LlavaConfig, LlavaLlamaForCausalLM)
-    cfg = Config(geometry=GEOMETRIES[name], mm_patch_merge_type=model_args.mm_patch_merge_type,
+    cfg = Config(geometry=geometry, mm_patch_merge_type=model_args.mm_patch_merge_type,
                       image_aspect_ratio=data_args.image_aspect_ratio, image_grid_pinpoints=data_args.image_grid_pinpoints,
                       tokenizer_model_max_length=training_args.model_max_length,
-                      unfreeze_mm_vision_tower="mm_vision_tower" in parts, lora=lora, freeze_lm=projector_only)
+                      unfreeze_mm_vision_tower="mm_vision_tower" in parts, lora=lora, freeze_lm=projector_only,
+                      train_embed_tokens=projector_only and model_args.mm_use_im_start_end)
+    cfg._name_or_path = model_args.model_name_or_path
     model = Model(cfg, device=f"cuda:{local}", process_group=pg, init="fast")
+    if true_vocab != geometry["lm"]["vocab"]:
+        model.engine.resize_token_embeddings(true_vocab)
+    if lm_dir:
+        from ...checkpoint_io import load_pretrained
+        load_pretrained(model.engine, lm_path=lm_dir, tower_path=tower_dir)     # raises if any LM / tower tensor is missing
     model.config.use_cache = False
     model.get_model().initialize_vision_modules(model_args)
     if model_args.version in conversation_lib.conv_templates:
@@ -530,6 +575,7 @@ def train(attn_implementation=None, argv=None, tokenizer=None):
         import transformers
         tokenizer = transformers.AutoTokenizer.from_pretrained(model_args.model_name_or_path, cache_dir=training_args.cache_dir,
                                                                 model_max_length=training_args.model_max_length, padding_side="right", use_fast=False)
+    model.config.tokenizer_padding_side = model.engine.padding_side = getattr(tokenizer, "padding_side", "right")   # train/train.py:1600
     # train/train.py:1678-1679: optional extra tokens grow the embedding tables (needs a tokenizer with add_tokens / __len__;
     # the RadVLM script passes --mm_use_im_patch_token False and no start/end tokens, so this is normally a no-op)
     model.config.mm_use_im_patch_token = model_args.mm_use_im_patch_token
@@ -543,6 +589,10 @@ def train(attn_implementation=None, argv=None, tokenizer=None):
     data_args.is_multimodal = True
     data_args.mm_use_im_start_end = model_args.mm_use_im_start_end
     module = make_supervised_data_module(tokenizer=tokenizer, data_args=data_args)
+    # the switches the trainer's checkpoint policy reads (train/train.py:1578-1611 copies them onto training_args)
+    training_args.tune_mm_mlp_adapter = model_args.tune_mm_mlp_adapter
+    training_args.mm_tunable_parts = model_args.mm_tunable_parts
+    training_args.use_im_start_end = model_args.mm_use_im_start_end
     trainer = LLaVATrainer(model=model, tokenizer=tokenizer, args=training_args, **module)
     # auto-resume like the reference (train/train.py:1699-1702): continue from the newest checkpoint-* of output_dir
     has_ckpt = bool(training_args.output_dir) and os.path.isdir(training_args.output_dir) and any(
@@ -550,7 +600,14 @@ def train(attn_implementation=None, argv=None, tokenizer=None):
     state = trainer.train(resume_from_checkpoint=True if has_ckpt else None)
     if rank == 0 and training_args.output_dir:
         os.makedirs(training_args.output_dir, exist_ok=True)
-        model.save_pretrained(training_args.output_dir)
+        if trainer._adapter_only() and not lora:
+            # safe_save_model_for_hf_trainer (train/train.py:258-289): projector-only runs save mm_projector.bin alone
+            keys = ["mm_projector", "vision_resampler"] + (["embed_tokens", "embed_in"] if model_args.mm_use_im_start_end else [])
+            torch.save({k: v.detach().clone().cpu() for k, v in model.state_dict().items() if any(m in k for m in keys)},
+                       os.path.join(training_args.output_dir, "mm_projector.bin"))
+            model.save_config(training_args.output_dir)
+        else:
+            model.save_pretrained(training_args.output_dir)      # LoRA: adapter + non_lora_trainables.bin (train/train.py:1708-1717)
     if world > 1:
         torch.distributed.destroy_process_group()
     return state

@@ -27,16 +27,22 @@ def run_smoke():
     eng.backward()
     eng.optimizer_step(lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
     torch.cuda.synchronize()
-    # checker: CPU oracle on the same inputs (test infrastructure, not the product path)
+    # checker: CPU oracle on the same inputs (test infrastructure, not the product path), in two modes: fp32 (the reference's own
+    # arithmetic; bf16 quantisation included in the distance) and with the kernels' bf16 store points (kernel error proper)
+    from oracle import bf16_emulation as E
     from oracle import llava_oracle as O
     P = O.make_params(geo, seed=0)
-    ref_loss, ref_logits, _ = O.llava_forward(P, geo, torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"]),
-                                              torch.from_numpy(g["labels"]), images)
+    a = (torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"]), torch.from_numpy(g["labels"]), images)
+    with torch.no_grad():
+        ref_loss, ref_logits, _ = O.llava_forward(P, geo, *a)
+    emu_loss, emu_logits, _ = E.llava_forward(P, geo, *a, emulate=True)
     m = torch.from_numpy(g["splice_attention_mask"])
     got = eng.last_logits.cpu()[m]
-    ref = ref_logits.detach()[m]
-    err = float((got - ref).abs().max() / ref.abs().max())
-    dl = abs(float(loss) - float(ref_loss))
-    print(f"smoke: loss {float(loss):.5f} (oracle {float(ref_loss):.5f}), logits rel-inf err {err:.3e}")
-    assert dl < 2e-2 and err < 5e-2, (dl, err)
+    rel = lambda x, y: float((x - y).abs().max() / y.abs().max())
+    err32, err16 = rel(got, ref_logits[m]), rel(got, emu_logits[m])
+    d32, d16 = abs(float(loss) - float(ref_loss)), abs(float(loss) - float(emu_loss))
+    print(f"smoke: loss {float(loss):.5f} (oracle fp32 {float(ref_loss):.5f}, bf16-emulated {float(emu_loss):.5f}); logits rel-inf err "
+          f"{err16:.3e} vs the bf16-emulated oracle, {err32:.3e} vs fp32 (emulated-vs-fp32 floor {rel(emu_logits[m], ref_logits[m]):.3e})")
+    assert d16 < 1e-3 and err16 < 1e-3, (d16, err16)
+    assert d32 < 5e-3 and err32 < 1.5e-2, (d32, err32)
     assert bool(torch.isfinite(eng.lm.flat.float()).all())

@@ -139,7 +139,7 @@ def merged_feature_rows(row0, n_tiles, side, merge_type="flat", aspect="square",
     return out
 
 
-def build_splice_plan(input_ids, attention_mask, labels, feature_rows, n_feat_rows, max_len=None):
+def build_splice_plan(input_ids, attention_mask, labels, feature_rows, n_feat_rows, max_len=None, padding_side="right"):
     """input_ids/labels int64 [B,T], attention_mask bool [B,T] (numpy); feature_rows: per-sample merged index arrays.
 
     Returns dict with
@@ -147,6 +147,7 @@ def build_splice_plan(input_ids, attention_mask, labels, feature_rows, n_feat_ro
       n_feat_rows is image_newline), labels [B,S], attention_mask [B,S], feat_pos int32 [n_feat_rows] (sequence row
       where each projector row landed, -1 if unused), newline_pos int32 [...], and the embedding CSR
       (tok_ids, tok_off, tok_pos) grouping sequence rows by token id (for the no-atomics embedding gradient).
+    padding_side "left" (config.tokenizer_padding_side, llava_arch.py:520-524): shorter samples sit at the END of their row.
     """
     B = input_ids.shape[0]
     seqs, labs = [], []
@@ -181,7 +182,12 @@ def build_splice_plan(input_ids, attention_mask, labels, feature_rows, n_feat_ro
     lens = np.zeros(B, dtype=np.int32)
     for b, (s, l) in enumerate(zip(seqs, labs)):
         n = s.shape[0]
-        idx[b, :n], L[b, :n], M[b, :n], lens[b] = s, l, True, n
+        lens[b] = n
+        if padding_side == "left":
+            if n:
+                idx[b, S - n:], L[b, S - n:], M[b, S - n:] = s, l, True
+        else:
+            idx[b, :n], L[b, :n], M[b, :n] = s, l, True
     flat = idx.reshape(-1)
     feat_pos = np.full(n_feat_rows, -1, dtype=np.int32)
     is_feat = flat <= -2

@@ -75,7 +75,7 @@ def build_reference_model(mods, geo, seed=0, merge_type="flat", aspect="square",
     return model
 
 
-def make_batch(geo, spec, seed_img=1, seed_ids=2, tiles=None):
+def make_batch(geo, spec, seed_img=1, seed_ids=2, tiles=None, left=False):
     """spec: list of (n_ids, image_pos or None, n_ignored_prefix)."""
     v = geo["vision"]
     V = geo["lm"]["vocab"]
@@ -98,9 +98,10 @@ def make_batch(geo, spec, seed_img=1, seed_ids=2, tiles=None):
         else:
             images.append(np.zeros((3, v["image"], v["image"]), dtype=np.float32))
             modalities.append("text")
-        ids[i, :n] = row
-        labels[i, :n] = lab
-        mask[i, :n] = True
+        sl = slice(T - n, T) if left else slice(0, n)      # left: what the collator builds for tokenizer.padding_side == "left"
+        ids[i, sl] = row
+        labels[i, sl] = lab
+        mask[i, sl] = True
     return ids, labels, mask, images, modalities
 
 
@@ -168,12 +169,13 @@ def build_reference_qwen_model(mods, geo, seed=0, merge_type="flat", aspect="squ
 
 
 def run_e2e(mods, geo_name, spec, out_name, grads_full=(), merge_type="flat", aspect="square", pinpoints=None,
-            tiles=None, image_sizes=None, unfreeze_tower=False, builder=None, slices=False):
+            tiles=None, image_sizes=None, unfreeze_tower=False, builder=None, slices=False, padding_side="right"):
     geo = GEOMETRIES[geo_name]
     model = (builder or build_reference_model)(mods, geo, merge_type=merge_type, aspect=aspect, pinpoints=pinpoints)
     if unfreeze_tower:  # mm_tunable_parts contains mm_vision_tower (train/train.py:1658-1661)
         model.get_model().get_vision_tower().vision_tower.requires_grad_(True)
-    ids, labels, mask, images, modalities = make_batch(geo, spec, tiles=tiles)
+    model.config.tokenizer_padding_side = padding_side      # train/train.py copies tokenizer.padding_side here; llava_arch.py:520-524
+    ids, labels, mask, images, modalities = make_batch(geo, spec, tiles=tiles, left=padding_side == "left")
     imgs = [torch.from_numpy(x) for x in images]
     sizes = image_sizes or [[geo["vision"]["image"]] * 2 for _ in images]
     with torch.no_grad():
@@ -431,5 +433,10 @@ if __name__ == "__main__":
         tiles = [1 + int(np.prod(mods["mm_utils"].get_anyres_image_grid_shape(sz, pin, 56))) for sz in sizes]
         run_e2e(mods, "toy", [(14, 4, 6), (10, 2, 3)], "toy_maxpool_e2e", merge_type="spatial_maxpool2x2", aspect="anyres", pinpoints=pin,
                 tiles=tiles, image_sizes=sizes, slices=True, grads_full=("model.mm_projector.2.weight",))
+    if "leftpad" in which:
+        # tokenizer_padding_side = "left" (llava_arch.py:520-524): short samples sit at the end of their row; position_ids are
+        # discarded in training (:534-545), so every row keeps positions arange(S)
+        run_e2e(mods, "toy", [(20, 5, 8), (12, 3, 4), (9, None, 2)], "toy_leftpad_e2e", padding_side="left",
+                grads_full=("model.mm_projector.0.weight", "model.layers.0.self_attn.q_proj.weight", "lm_head.weight", "model.embed_tokens.weight"))
     if "cfg1" in which:
         run_e2e(mods, "config1", [(48, 35, 40)], "config1_e2e")

@@ -1,0 +1,172 @@
+"""GPU parity at the shapes the bench and the target workloads really run (-m gpu), through the C ABI:
+
+  * the 256x256 GEMM at M = 22528 token rows (32 pairs x 704) against every weight of the 7B decoder, in the three operand
+    forms of forward (NT), dgrad (NN) and wgrad (TT): 512 sampled output rows against an fp32 CPU product, and the tail-split
+    launch shape (MODE 3) against the plain one (MODE 0) on the full output;
+  * causal attention forward + backward at S = 3056 (BASELINE config 4) and at S = 7499 with 28 query / 4 key-value heads
+    (the RadVLM recipe shape, both dK/dV launch shapes);
+  * one LoRA decoder layer at LLaVA-1.5-13B widths (d = 5120, 40 heads, ffn 13824, r = 64; BASELINE config 5).
+Operands are drawn on the device (torch's generator is plumbing here: a 22528 x 11008 operand from the portable generator would
+take minutes); the checker is the CPU oracle / an fp32 CPU matmul on rows copied back.  Tolerance as in test_kernels_gpu.py:
+bf16 outputs max|d| / max|ref| <= 2^-7, fp32 outputs <= 1e-5 (summation order).
+"""
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2.0 ** -7
+M_BENCH = 22528          # 32 pairs x 704 tokens
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from radvlm_amd import lib, ops as _ops
+    lib.load()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    return _ops
+
+
+def relerr(got, ref):
+    got, ref = got.detach().float().cpu().double(), ref.detach().float().cpu().double()
+    return float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
+
+
+def _randn(shape, seed, std=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(shape, generator=g, device="cuda", dtype=torch.float32) * std).to(torch.bfloat16)
+
+
+def _rows(n, count, seed):
+    """`count` sampled row indices of [0, n): the first / last tile rows and a seeded spread in between."""
+    g = torch.Generator().manual_seed(seed)
+    mid = torch.randint(0, n, (count - 96,), generator=g)
+    return torch.unique(torch.cat([torch.arange(0, 48), torch.arange(n - 48, n), mid]))
+
+
+# (form, M, N, K): forward y = x W^T; dgrad dx = dy W; wgrad dW = dy^T x -- the decoder's weights: qkv 12288x4096, o 4096x4096,
+# gate|up 22016x4096, down 4096x11008, lm_head 32000x4096
+BENCH_GEMMS = [
+    ("nt", M_BENCH, 12288, 4096), ("nt", M_BENCH, 4096, 4096), ("nt", M_BENCH, 22016, 4096), ("nt", M_BENCH, 4096, 11008),
+    ("nt", M_BENCH, 32000, 4096),
+    ("nn", M_BENCH, 4096, 12288), ("nn", M_BENCH, 4096, 22016), ("nn", M_BENCH, 11008, 4096), ("nn", M_BENCH, 4096, 32000),
+    ("tt", 12288, 4096, M_BENCH), ("tt", 22016, 4096, M_BENCH), ("tt", 4096, 11008, M_BENCH), ("tt", 32000, 4096, M_BENCH),
+]
+
+
+@pytest.mark.parametrize("form,M,N,K", BENCH_GEMMS)
+def test_gemm_bench_shapes(ops, form, M, N, K):
+    from radvlm_amd import lib
+    ta, tb = form == "tt", form in ("nn", "tt")
+    a = _randn((K, M) if ta else (M, K), 1, 0.5)          # stored [K, M] when read contraction-major
+    b = _randn((K, N) if tb else (N, K), 2, 0.5)
+    out = ops.gemm(a, b, ta=ta, tb=tb)
+    assert out.shape == (M, N)
+    rows = _rows(M, 512, 3)
+    a_rows = (a[:, rows.cuda()].t() if ta else a[rows.cuda()]).float().cpu()
+    bf = (b if tb else b.t()).float().cpu()               # [K, N]
+    ref = a_rows @ bf
+    assert relerr(out[rows.cuda()], ref) < TOL
+    # the tail-split launch shape (last round of 256 CUs at most half full -> its tiles run as K-slices + a reduce) against the
+    # plain one, full output in fp32: equal up to summation order
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    if 0 < tiles % 256 <= 128 and K >= 2048:
+        l = lib.load()
+        try:
+            l.rv_gemm_select_kernel(20)
+            plain = ops.gemm(a, b, ta=ta, tb=tb, out_dtype=torch.float32)
+            l.rv_gemm_select_kernel(21)
+            split = ops.gemm(a, b, ta=ta, tb=tb, out_dtype=torch.float32)
+        finally:
+            l.rv_gemm_select_kernel(21)
+        scale = float(plain.abs().max())
+        assert float((split - plain).abs().max()) <= 1e-5 * scale
+        assert relerr(plain[rows.cuda()], ref) < 1e-5
+
+
+def _attn_oracle(q, k, v, dout, H, Hkv, causal=True):
+    """fp32 oracle attention fwd+bwd, one key/value head group at a time (a 28-head S=7499 score tensor would be 6.3 GB)."""
+    from oracle import llava_oracle as O
+    rep = H // Hkv
+    outs, dqs, dks, dvs = [], [], [], []
+    for hk in range(Hkv):
+        qg = q[:, hk * rep:(hk + 1) * rep].clone().requires_grad_(True)
+        kg = k[:, hk:hk + 1].clone().requires_grad_(True)
+        vg = v[:, hk:hk + 1].clone().requires_grad_(True)
+        o = O.attention(qg, kg.expand(-1, rep, -1, -1), vg.expand(-1, rep, -1, -1), lens=None, causal=causal)
+        o.backward(dout[:, hk * rep:(hk + 1) * rep])
+        outs.append(o.detach()), dqs.append(qg.grad), dks.append(kg.grad), dvs.append(vg.grad)
+    return torch.cat(outs, 1), torch.cat(dqs, 1), torch.cat(dks, 1), torch.cat(dvs, 1)
+
+
+@pytest.mark.parametrize("S,H,Hkv", [(3056, 2, 2), (7499, 28, 4)])
+def test_attention_long_sequences(ops, S, H, Hkv):
+    B, hd = 1, 128
+    d, kvd = H * hd, Hkv * hd
+    s_pad = (S + 63) // 64 * 64
+    qkv = _randn((B * S, d + 2 * kvd), 21)
+    dout = _randn((B * S, d), 22)
+    hq = lambda t: t.float().cpu().view(B, S, H, hd).transpose(1, 2)
+    hk = lambda t: t.float().cpu().view(B, S, Hkv, hd).transpose(1, 2)
+    ref_o, ref_dq, ref_dk, ref_dv = _attn_oracle(hq(qkv[:, :d]), hk(qkv[:, d:d + kvd]), hk(qkv[:, d + kvd:]), hq(dout), H, Hkv)
+    gq, gk, gv = qkv[:, :d], qkv[:, d:d + kvd], qkv[:, d + kvd:]
+    vT = ops.transpose_heads(gv, B, S, Hkv, hd, s_pad)
+    out, lse = ops.attn_fwd(gq, gk, vT, B, S, H, hd, s_pad, True, kv_heads=Hkv)
+    assert relerr(out.view(B, S, H, hd).transpose(1, 2), ref_o) < TOL
+    for use_ws in ((False, True) if Hkv != H else (True,)):
+        dq, dk, dv = ops.attn_bwd(gq, gk, gv, out, dout, lse, B, S, H, hd, s_pad, True, kv_heads=Hkv, use_workspace=use_ws)
+        assert relerr(dq.view(B, S, H, hd).transpose(1, 2), ref_dq) < 2 * TOL, use_ws
+        assert relerr(dk.view(B, S, Hkv, hd).transpose(1, 2), ref_dk) < 2 * TOL, use_ws
+        assert relerr(dv.view(B, S, Hkv, hd).transpose(1, 2), ref_dv) < 2 * TOL, use_ws
+
+
+def test_lora_layer_at_13b_widths():
+    """BASELINE config 5 widths: one Vicuna-13B decoder layer (d 5120, 40 heads x 128, ffn 13824) with r = 64 adapters on its seven
+    linears (fused second-operand-pair GEMM, split-K dA/dB), ViT-L/14-336 widths at 2 executed layers, 2 x 704 tokens, against the
+    oracle's LoRA restatement (peft absent upstream: parity unpinned for the adapter formula itself, see oracle.apply_lora)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import llava_oracle as O
+    from radvlm_amd.engine import LlavaEngine
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    geo = {"vision": dict(d=1024, heads=16, ffn=4096, layers=3, image=336, patch=14),
+           "lm": dict(d=5120, heads=40, ffn=13824, layers=1, vocab=2048)}
+    r, alpha = 64, 16
+    g = torch.Generator().manual_seed(9)
+    B, T = 2, 129
+    ids = torch.randint(3, 2048, (B, T), generator=g)
+    labels = ids.clone()
+    labels[:, :64] = -100
+    ids[:, 35] = -200
+    labels[:, 35] = -100
+    mask = torch.ones(B, T, dtype=torch.bool)
+    images = [torch.randn(3, 336, 336, generator=g).to(torch.bfloat16).float() for _ in range(B)]
+    eng = LlavaEngine(geo, device="cuda:0", init="fast", seed=7, lora=dict(r=r, alpha=alpha, dropout=0.0))
+    L = {}
+    for n in eng.lm.names():
+        if ".lora_B" in n:                      # peft starts B at zero: give it values so that every adapter path carries signal
+            eng.lm.view(n).normal_(0, 0.02, generator=torch.Generator(device="cuda").manual_seed(len(L)))
+        if ".lora_" in n:
+            L[n] = eng.lm.view(n).float().cpu().requires_grad_(True)
+    loss = eng.forward(ids.numpy(), mask.numpy(), labels.numpy(), images, want_logits=True)
+    logits = eng.last_logits.cpu()
+    eng.backward()
+    torch.cuda.synchronize()
+    P = {k: v.float().cpu() for k, v in eng.state_dict().items() if ".lora_" not in k}
+    proj = [k for k in P if "mm_projector" in k]
+    for k in proj:
+        P[k].requires_grad_(True)
+    rl, rlog, aux = O.llava_forward(O.apply_lora(P, L, geo, alpha / r), geo, ids, mask, labels, images)
+    rl.backward()
+    assert aux["inputs_embeds"].shape[1] == 704
+    assert abs(float(loss) - float(rl)) < 1e-2, (float(loss), float(rl))
+    assert relerr(logits, rlog.detach()) < 1.5e-2
+    for n, ref in list(L.items()) + [(k, P[k]) for k in proj]:
+        got = eng.G(n).float().cpu()
+        rel = float((got - ref.grad).norm() / ref.grad.norm().clamp_min(1e-12))
+        assert rel < 6e-2, (n, rel)

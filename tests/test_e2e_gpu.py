@@ -1,9 +1,11 @@
 """End-to-end GPU parity (-m gpu): the HIP engine (bf16, through the C ABI) against golden vectors of the reference
 (tests/golden/*.npz, CPU fp32) on the same synthetic inputs and portable weights.
 
-Tolerances (bf16 compute vs an fp32 reference; stated per check):
-  loss |d| <= 5e-3 (toy) / 2e-2 (config 1: 24 bf16 layers, 32000-way bf16 logits); logits ||d||_inf / ||ref||_inf <= 3e-2 over valid positions;
-  per-parameter gradient: ||d||_2 / ||ref||_2 <= 5e-2 on the fully stored tensors, norms within 5 %.
+Tolerances, two references (stated per check):
+  vs the bf16-EMULATING oracle (oracle/bf16_emulation.py: the oracle with the kernels' bf16 store points) -- kernel error proper, at
+    the contract's figures: logits ||d||_inf / ||ref||_inf <= 1e-3 and loss |d| <= 1e-3 (test_bf16_emulated_parity);
+  vs the fp32 reference goldens -- bf16 quantisation included, gated at <= 2x the measured values: logits <= 1.5e-2, loss |d| <= 5e-3
+    (toy) / 1.2e-2 (config 1: 24 bf16 layers, 32000-way logits); per-parameter gradient ||d||_2 / ||ref||_2 <= 5e-2, norms within 5 %.
 """
 import json
 import os
@@ -15,6 +17,8 @@ import torch
 from radvlm_amd.config import GEOMETRIES
 
 pytestmark = pytest.mark.gpu
+
+LOGITS_FP32_TOL = 1.5e-2      # vs the fp32 reference: <= 2x the measured 7.8e-3 (= the bf16 quantisation floor, 8.3e-3 emulated)
 
 
 def _engine(name, **kw):
@@ -49,7 +53,7 @@ def _check(eng, g, meta, loss, logits, plan, full=True, loss_tol=5e-3, grad_rel=
     if full:
         ref = torch.from_numpy(g["logits"])
         err = float((logits[m] - ref[m]).abs().max() / ref[m].abs().max())
-        assert err < 3e-2, err
+        assert err < LOGITS_FP32_TOL, err
     worst = 0.0
     for k, want in meta["grad_norms"].items():
         if want is None:
@@ -107,7 +111,7 @@ def _check_slices(eng, g, logits, images):
     ref = torch.from_numpy(g["logits_slice"])
     got = logits[:, ::7, ::997]
     m = torch.from_numpy(g["splice_attention_mask"])[:, ::7]      # padding rows carry no defined logits in packed batches
-    assert float((got - ref)[m].abs().max() / float(g["logits_absmax"].max())) < 3e-2
+    assert float((got - ref)[m].abs().max() / float(g["logits_absmax"].max())) < LOGITS_FP32_TOL
 
 
 def test_toy_qwen2_siglip(golden_dir):
@@ -180,10 +184,48 @@ def test_config1(golden_dir):
     g, meta, images = _golden(golden_dir, "config1_e2e")
     eng = _engine("config1")
     loss, logits, plan = _run(eng, g, images)
-    _check(eng, g, meta, loss, logits, plan, full=False, loss_tol=2e-2)  # 12+12 layers, V=32000, bf16 logits
+    _check(eng, g, meta, loss, logits, plan, full=False, loss_tol=1.2e-2)  # 12+12 layers, V=32000, bf16-stored logits feed the loss
     ref = torch.from_numpy(g["logits_slice"])
     got = logits[:, ::7, ::997]
-    assert float((got - ref).abs().max() / float(g["logits_absmax"].max())) < 3e-2
+    assert float((got - ref).abs().max() / float(g["logits_absmax"].max())) < 2.5e-2      # emulated bf16 floor: 1.9e-2
+
+
+BF16_EMU_RESULTS = {}
+
+
+@pytest.mark.parametrize("name,geo_name", [("toy_e2e", "toy"), ("toy_qwen_e2e", "toy_qwen"), ("config1_e2e", "config1")])
+def test_bf16_emulated_parity(golden_dir, name, geo_name):
+    """The contract's gate, stated against the right reference: the HIP engine vs the oracle run with bf16 STORE POINTS
+    (oracle/bf16_emulation.py), on the reference-generated golden inputs.  ||logits - emu||_inf / ||emu||_inf <= 1e-3 and
+    |loss - emu| <= 1e-3 are kernel error proper; the emulated-vs-fp32 distance (the quantisation floor every bf16 run has) and the
+    HIP-vs-fp32 distance are recorded beside them (gpurun_out/bf16_parity.json) and must agree within 30 %: the engine is as close to
+    fp32 as an ideal bf16 implementation of the same store points."""
+    from oracle import bf16_emulation as E
+    from oracle import llava_oracle as O
+    g, meta, images = _golden(golden_dir, name)
+    geo = GEOMETRIES[geo_name]
+    eng = _engine(geo_name, packed=False)
+    loss = float(eng.forward(g["input_ids"], g["attention_mask"], g["labels"], images, want_logits=True))
+    logits = eng.last_logits.cpu()
+    eng.ctx = None
+    P = O.make_params(geo, seed=0)
+    a = (torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"]), torch.from_numpy(g["labels"]), images)
+    le, lge, aux = E.llava_forward(P, geo, *a, emulate=True)
+    with torch.no_grad():
+        l0, lg0, _ = O.llava_forward(P, geo, *a)
+    m = aux["attention_mask"]
+    relinf = lambda x, y: float((x[m] - y[m]).abs().max() / y[m].abs().max())
+    rel2 = lambda x, y: float((x[m] - y[m]).norm() / y[m].norm())
+    rec = dict(hip_vs_emu_inf=relinf(logits, lge), hip_vs_emu_l2=rel2(logits, lge), emu_vs_fp32_inf=relinf(lge, lg0), emu_vs_fp32_l2=rel2(lge, lg0),
+               hip_vs_fp32_inf=relinf(logits, lg0), hip_vs_fp32_l2=rel2(logits, lg0), loss_hip=loss, loss_emu=float(le), loss_fp32=float(l0))
+    BF16_EMU_RESULTS[name] = rec
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/bf16_parity.json", "w") as f:
+        json.dump(BF16_EMU_RESULTS, f, indent=1)
+    print(name, rec)
+    assert rec["hip_vs_emu_inf"] <= 1e-3, rec
+    assert abs(loss - float(le)) <= 1e-3, rec
+    assert rec["hip_vs_fp32_l2"] <= 1.3 * rec["emu_vs_fp32_l2"], rec
 
 
 def test_grad_accumulation_and_optimizer_step(golden_dir):
@@ -330,8 +372,10 @@ def test_toy_lora(golden_dir, geo_name, golden):
 
 def test_full_width_7b_layer_geometry():
     """BASELINE config-2 widths (d=4096, 32 heads x 128, ffn=11008; ViT-L/14-336 widths) at reduced depth (1 decoder layer,
-    2 ViT layers, vocab 2048) so that the CPU oracle finishes in seconds: exercises the 256x256 GEMM in all operand forms,
-    hd=128 causal attention at S=704 and the 577-token ViT attention at their real sizes."""
+    2 ViT layers, vocab 2048) so that the CPU oracle finishes in seconds: hd=128 causal attention at S=704, the 577-token ViT
+    attention and every GEMM at its real N and K.  With M = 1408 token rows the forward (NT) GEMMs have too few tiles for the
+    256x256 kernel and run on the 128x128 one; the contraction-major dgrad / wgrad forms run on the 256x256 kernel.  The 256x256 NT
+    path at the bench's M = 22528 is covered by tests/test_bench_shapes_gpu.py."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from oracle import llava_oracle as O
@@ -366,7 +410,7 @@ def test_full_width_7b_layer_geometry():
     assert aux["inputs_embeds"].shape[1] == 704
     assert abs(float(loss) - float(rl)) < 1e-2, (float(loss), float(rl))
     ref = rlog.detach()[plan_mask]
-    assert float((logits[plan_mask] - ref).abs().max() / ref.abs().max()) < 3e-2
+    assert float((logits[plan_mask] - ref).abs().max() / ref.abs().max()) < LOGITS_FP32_TOL
     for k in ("lm_head.weight", "model.layers.0.mlp.down_proj.weight", "model.layers.0.mlp.gate_proj.weight",
               "model.layers.0.self_attn.q_proj.weight", "model.layers.0.self_attn.v_proj.weight", "model.layers.0.self_attn.o_proj.weight",
               "model.layers.0.input_layernorm.weight", "model.mm_projector.0.weight", "model.mm_projector.2.bias", "model.embed_tokens.weight"):
@@ -410,7 +454,7 @@ def test_full_width_qwen2_siglip_layer_geometry():
     assert aux["inputs_embeds"].shape[1] == 729 + T - 1
     assert abs(float(loss) - float(rl)) < 1e-2, (float(loss), float(rl))
     ref = rlog.detach()[plan_mask]
-    assert float((logits[plan_mask] - ref).abs().max() / ref.abs().max()) < 3e-2
+    assert float((logits[plan_mask] - ref).abs().max() / ref.abs().max()) < LOGITS_FP32_TOL
     vp = "model.vision_tower.vision_tower.vision_model."
     for k in ("lm_head.weight", "model.layers.0.mlp.down_proj.weight", "model.layers.0.self_attn.q_proj.weight",
               "model.layers.0.self_attn.k_proj.weight", "model.layers.0.self_attn.v_proj.bias", "model.layers.0.self_attn.o_proj.weight",
@@ -535,7 +579,7 @@ def test_checkpoint_resume_is_bit_identical(golden_dir, tmp_path):
 
     full, s_full = run(tmp_path / "a", 4, 2, None)          # 4 steps, checkpoints after steps 2 and 4
     ck = tmp_path / "a" / "checkpoint-2"
-    assert sorted(os.listdir(ck)) == ["mm_projector.bin", "model.safetensors", "optimizer.safetensors", "trainer_state.json"]
+    assert sorted(os.listdir(ck)) == ["config.json", "mm_projector.bin", "model.safetensors", "optimizer.safetensors", "trainer_state.json"]
     proj = torch.load(ck / "mm_projector.bin", map_location="cpu", weights_only=True)
     assert sorted(proj) == ["model.mm_projector.0.bias", "model.mm_projector.0.weight", "model.mm_projector.2.bias", "model.mm_projector.2.weight"]
     resumed, s_res = run(tmp_path / "b", 4, 0, str(ck))     # fresh model, continue from step 2 of the same 4-step schedule

@@ -238,3 +238,25 @@ def test_e2e_toy_maxpool2x2(golden_dir):
     g, meta, P, loss, logits, aux = _run_e2e(golden_dir, "toy_maxpool_e2e")
     _check_common(g, meta, P, loss, logits, aux)
     _check_slices(g, P, logits, aux)
+
+
+@pytest.mark.parametrize("name,geo_name", [("toy_e2e", "toy"), ("toy_qwen_e2e", "toy_qwen"), ("config1_e2e", "config1")])
+def test_bf16_emulation_reduces_to_oracle(golden_dir, name, geo_name):
+    """oracle/bf16_emulation.py is the oracle's forward with bf16 store points.  Pin: with the rounding switched off it must BE the
+    oracle (<= 1e-5, hence the reference's golden loss); with it on, the distance to fp32 is the quantisation floor of the storage
+    format -- reported by the GPU tests next to the HIP numbers, bounded here so a broken emulation cannot hide behind it."""
+    from oracle import bf16_emulation as E
+    from radvlm_amd.smoke import load_golden_batch
+    geo = GEOMETRIES[geo_name]
+    g, images = load_golden_batch(name)
+    P = O.make_params(geo, seed=0)
+    a = (torch.from_numpy(g["input_ids"]), torch.from_numpy(g["attention_mask"]), torch.from_numpy(g["labels"]), images)
+    with torch.no_grad():
+        l0, lg0, _ = O.llava_forward(P, geo, *a)
+    l1, lg1, aux = E.llava_forward(P, geo, *a, emulate=False)
+    m = aux["attention_mask"]
+    assert abs(float(l1) - float(g["loss"])) < 2e-5 and abs(float(l1) - float(l0)) < 1e-5
+    assert float((lg1[m] - lg0[m]).abs().max() / lg0[m].abs().max()) < 1e-5
+    l2, lg2, _ = E.llava_forward(P, geo, *a, emulate=True)
+    floor = float((lg2[m] - lg0[m]).abs().max() / lg0[m].abs().max())
+    assert 1e-3 < floor < 3e-2 and abs(float(l2) - float(l0)) < 1e-2, (floor, float(l2), float(l0))

@@ -1,0 +1,252 @@
+"""GPU tests (-m gpu) of the training-entry behaviours the reference script relies on: train() starts from the saved checkpoint it is
+pointed at, gradient accumulation averages, LoRA checkpoints resume, left-padded batches, and the pretraining stage that trains the
+input embeddings of the added <im_start>/<im_end> tokens (llava_arch.py:557-597)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from radvlm_amd.config import GEOMETRIES
+
+pytestmark = pytest.mark.gpu
+
+
+class _Ids:
+    def __init__(self, ids):
+        self.input_ids = ids
+
+
+class Tok:
+    """Character tokenizer with the attributes the data path reads (ids < 1000 = the toy vocabulary)."""
+    bos_token_id, pad_token_id, model_max_length, legacy, padding_side = 1, 0, 256, True, "right"
+
+    def __init__(self):
+        self.extra = []
+
+    def __call__(self, s, **kw):
+        ids = [1]
+        for k, piece in enumerate(s.split("</s>")):
+            if k:
+                ids.append(2)
+            ids.extend(3 + (ord(c) % 900) for c in piece)
+        return _Ids(ids)
+
+    def add_tokens(self, toks, special_tokens=False):
+        new = [t for t in toks if t not in self.extra]
+        self.extra += new
+        return len(new)
+
+    def __len__(self):
+        return 1000 + len(self.extra)
+
+
+def _dataset(tmp_path, n=8, seed=1):
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    recs = []
+    for i in range(n):
+        Image.fromarray(rng.integers(0, 255, (64, 80, 3), dtype=np.uint8)).save(tmp_path / f"im{i}.png")
+        recs.append({"id": f"s{i}", "image": f"im{i}.png", "conversations": [{"from": "human", "value": "<image>\nWhat is it?"},
+                                                                            {"from": "gpt", "value": f"Finding number {i} " + "x" * i}]})
+    (tmp_path / "d.json").write_text(json.dumps(recs))
+    return str(tmp_path / "d.json")
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+
+
+def _golden(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    meta = json.load(open(os.path.join(golden_dir, name + "_gradnorms.json")))
+    n = len([k for k in g.files if k.startswith("image") and k[5:].isdigit()])
+    return g, meta, [torch.from_numpy(g[f"image{i}"]) for i in range(n)]
+
+
+def test_gradient_accumulation_averages_the_micro_batches(golden_dir):
+    """HF Trainer back-propagates loss / gradient_accumulation_steps per micro-batch: two micro-batches of 2 (loss_scale 1/2) must leave
+    the gradients, hence the pre-clip norm max_grad_norm acts on, of ONE batch of the same 4 samples when the micro-batches hold
+    equally many label tokens (mean of means == mean)."""
+    _need_gpu()
+    from radvlm_amd.engine import LlavaEngine
+    geo = GEOMETRIES["toy"]
+    rng = np.random.default_rng(3)
+    T = 18
+    ids = rng.integers(3, 1000, size=(4, T), dtype=np.int64)
+    labels = ids.copy()
+    labels[:, :6] = -100                        # 12 label tokens per sample in every micro-batch
+    ids[:, 4] = -200
+    labels[:, 4] = -100
+    mask = np.ones_like(ids, dtype=bool)
+    images = [torch.randn(3, 56, 56, generator=torch.Generator().manual_seed(i)).to(torch.bfloat16) for i in range(4)]
+    whole = LlavaEngine(geo, device="cuda:0", init="portable", seed=0)
+    l4 = float(whole.forward(ids, mask, labels, images))
+    whole.backward()
+    acc = LlavaEngine(geo, device="cuda:0", init="portable", seed=0)
+    acc.loss_scale = 0.5
+    la = float(acc.forward(ids[:2], mask[:2], labels[:2], images[:2]))
+    acc.backward()
+    lb = float(acc.forward(ids[2:], mask[2:], labels[2:], images[2:]))
+    acc.backward()
+    torch.cuda.synchronize()
+    assert abs(0.5 * (la + lb) - l4) < 2e-3                 # the reported losses are never scaled
+    gw, ga = whole.grads.float(), acc.grads.float()
+    assert float((ga - gw).norm() / gw.norm()) < 2e-2
+    nw = float(whole.optimizer_step(lr=1e-3, max_grad_norm=1.0) or whole.last_grad_norm)
+    na = float(acc.optimizer_step(lr=1e-3, max_grad_norm=1.0) or acc.last_grad_norm)
+    assert abs(na - nw) < 2e-2 * nw
+    # and the un-averaged sum the trainer used to build is twice as large (what the advisor flagged)
+    summed = LlavaEngine(geo, device="cuda:0", init="portable", seed=0)
+    summed.forward(ids[:2], mask[:2], labels[:2], images[:2]); summed.backward()
+    summed.forward(ids[2:], mask[2:], labels[2:], images[2:]); summed.backward()
+    assert abs(float(summed.grads.float().norm()) / float(gw.norm()) - 2.0) < 0.05
+
+
+def _train_args(tmp_path, data, extra):
+    return ["--data_path", data, "--image_folder", str(tmp_path), "--image_aspect_ratio", "pad", "--version", "v1",
+            "--per_device_train_batch_size", "2", "--learning_rate", "1e-3", "--warmup_ratio", "0.0", "--mm_projector_type", "mlp2x_gelu",
+            "--mm_vision_select_layer", "-2", "--mm_use_im_patch_token", "False", "--model_max_length", "256"] + extra
+
+
+def test_train_starts_from_the_checkpoint_it_is_given(tmp_path):
+    """train() with --model_name_or_path DIR loads DIR's weights (reference: get_model -> from_pretrained, train/train.py:1358-1427): the
+    first logged loss is the loss of the saved model on that batch, not that of a random model; a hub name raises instead of silently
+    training random weights."""
+    _need_gpu()
+    from radvlm_amd.llava import conversation as conv_lib
+    from radvlm_amd.llava.model import LlavaConfig, LlavaLlamaForCausalLM
+    from radvlm_amd.llava.train.train import train
+    data = _dataset(tmp_path, n=2)
+    saved = LlavaLlamaForCausalLM(LlavaConfig(geometry=GEOMETRIES["toy"]), device="cuda:0", init="portable", seed=0)
+    ck = tmp_path / "base"
+    saved.save_pretrained(str(ck))
+    assert {"config.json", "model.safetensors"} <= set(os.listdir(ck))
+    try:
+        state = train(argv=_train_args(tmp_path, data, ["--model_name_or_path", str(ck), "--max_steps", "1", "--output_dir", str(tmp_path / "out")]),
+                      tokenizer=Tok())
+        first = state["log_history"][0]["loss"]
+        # the same batch through the saved model directly
+        from radvlm_amd.llava.mm_utils import ClipImageProcessor
+        from radvlm_amd.llava.train.train import DataArguments, make_supervised_data_module
+        da = DataArguments(data_path=data, image_folder=str(tmp_path), image_aspect_ratio="pad", is_multimodal=True)
+        da.image_processor, da.mm_use_im_start_end = ClipImageProcessor(56), False
+        mod = make_supervised_data_module(tokenizer=Tok(), data_args=da)
+        batch = mod["data_collator"]([mod["train_dataset"][0], mod["train_dataset"][1]])
+        want = float(saved(**batch).loss)
+        assert abs(first - want) < 1e-4, (first, want)
+        rand = LlavaLlamaForCausalLM(LlavaConfig(geometry=GEOMETRIES["toy"]), device="cuda:0", init="fast", seed=5)
+        assert abs(float(rand(**batch).loss) - want) > 1e-2
+        with pytest.raises(FileNotFoundError):
+            train(argv=_train_args(tmp_path, data, ["--model_name_or_path", "lmsys/vicuna-7b-v1.5", "--vision_tower", "openai/clip-vit-large-patch14-336",
+                                                    "--max_steps", "1"]), tokenizer=Tok())
+        # the output directory of the run is itself a loadable checkpoint
+        assert {"config.json", "model.safetensors"} <= set(os.listdir(tmp_path / "out"))
+    finally:
+        conv_lib.default_conversation = conv_lib.conv_templates["v1"]
+
+
+def test_lora_run_saves_the_reference_files_and_resumes(tmp_path):
+    """--lora_enable: the run leaves adapter_model.bin + adapter_config.json + non_lora_trainables.bin (train/train.py:1708-1717) and a
+    restarted run (auto-resume finds checkpoint-*, train.py:1699-1702) continues bit-identically instead of raising."""
+    _need_gpu()
+    from radvlm_amd.llava import conversation as conv_lib
+    from radvlm_amd.llava.train.train import train
+    data = _dataset(tmp_path, n=8)
+    common = ["--geometry", "toy", "--lora_enable", "True", "--lora_r", "8", "--lora_alpha", "16", "--lora_dropout", "0.05", "--save_steps", "2"]
+    try:
+        train(argv=_train_args(tmp_path, data, common + ["--max_steps", "4", "--output_dir", str(tmp_path / "a")]), tokenizer=Tok())
+        assert {"adapter_model.bin", "adapter_config.json", "non_lora_trainables.bin", "config.json"} <= set(os.listdir(tmp_path / "a"))
+        ad = torch.load(tmp_path / "a" / "adapter_model.bin", map_location="cpu", weights_only=True)
+        nl = torch.load(tmp_path / "a" / "non_lora_trainables.bin", map_location="cpu", weights_only=True)
+        assert "base_model.model.model.layers.0.self_attn.q_proj.lora_A.weight" in ad and ad["base_model.model.model.layers.1.mlp.down_proj.lora_B.weight"].shape == (256, 8)
+        assert sorted(nl) == ["base_model.model.model.mm_projector." + k for k in ("0.bias", "0.weight", "2.bias", "2.weight")]
+        cfg = json.load(open(tmp_path / "a" / "adapter_config.json"))
+        assert cfg["r"] == 8 and cfg["lora_alpha"] == 16 and cfg["peft_type"] == "LORA" and "q_proj" in cfg["target_modules"]
+        # second run: 2 steps, then a restart of the same command with max_steps 4 resumes from checkpoint-2
+        train(argv=_train_args(tmp_path, data, common + ["--max_steps", "2", "--output_dir", str(tmp_path / "b")]), tokenizer=Tok())
+        assert "checkpoint-2" in os.listdir(tmp_path / "b")
+        st = train(argv=_train_args(tmp_path, data, common + ["--max_steps", "4", "--output_dir", str(tmp_path / "b")]), tokenizer=Tok())
+        assert [r["step"] for r in st["log_history"]] == [1, 2, 3, 4]
+        ad2 = torch.load(tmp_path / "b" / "adapter_model.bin", map_location="cpu", weights_only=True)
+        for k in ad:
+            assert torch.equal(ad[k], ad2[k]), k
+    finally:
+        conv_lib.default_conversation = conv_lib.conv_templates["v1"]
+
+
+@pytest.mark.parametrize("packed", ["auto", False])
+def test_left_padding_against_reference_golden(golden_dir, packed):
+    """config.tokenizer_padding_side = 'left' (llava_arch.py:520-524) against a reference-generated fixture: splice labels / mask
+    bit-exact, loss / logits / gradients within the bf16 gates.  Short samples sit at the end of their row and keep positions
+    arange(S) (the reference discards the spliced position_ids in training)."""
+    _need_gpu()
+    from radvlm_amd.engine import LlavaEngine
+    g, meta, images = _golden(golden_dir, "toy_leftpad_e2e")
+    assert not g["attention_mask"][1, 0] and g["attention_mask"][1, -1]
+    eng = LlavaEngine(GEOMETRIES["toy"], device="cuda:0", init="portable", seed=0, padding_side="left", packed=packed)
+    loss = float(eng.forward(g["input_ids"], g["attention_mask"], g["labels"], images, want_logits=True))
+    logits = eng.last_logits.cpu()
+    plan = eng.ctx["plan"]
+    eng.backward()
+    torch.cuda.synchronize()
+    assert np.array_equal(plan["labels"], g["splice_labels"]) and np.array_equal(plan["attention_mask"], g["splice_attention_mask"])
+    assert abs(loss - float(g["loss"])) < 5e-3
+    m = torch.from_numpy(g["splice_attention_mask"])
+    ref = torch.from_numpy(g["logits"])
+    assert float((logits[m] - ref[m]).abs().max() / ref[m].abs().max()) < 1.5e-2
+    assert float(logits[~m].abs().max()) == 0.0                   # padding rows are never computed
+    for k, want in meta["grad_norms"].items():
+        if want is not None and k in eng.lm.offsets:
+            got = float(eng.G(k).float().norm())
+            assert abs(got - want) < 5e-2 * want + 1e-5, (k, got, want)
+    for k in g.files:
+        if k.startswith("grad::"):
+            ref_g = torch.from_numpy(g[k])
+            assert float((eng.G(k[6:]).float().cpu() - ref_g).norm() / ref_g.norm()) < 5e-2, k
+    # a label on the first token of a left-padded row would make the reference read a padding row's logits: refused
+    bad = g["labels"].copy()
+    first = int(np.argmax(g["attention_mask"][1]))
+    bad[1, first] = 7
+    with pytest.raises(ValueError, match="left padding"):
+        eng.forward(g["input_ids"], g["attention_mask"], bad, images)
+
+
+def test_pretraining_stage_with_start_end_tokens_trains_the_input_embeddings(golden_dir, tmp_path):
+    """tune_mm_mlp_adapter + mm_use_im_start_end (llava_arch.py:563-592): the tables grow by two mean-initialised rows, the INPUT
+    embeddings train together with the projector while lm_head and the decoder stay frozen, pretrain_mm_mlp_adapter restores the two
+    new rows, and the adapter-only save holds the projector + embed_tokens (llava_trainer.py:446-455 with use_im_start_end)."""
+    _need_gpu()
+    from types import SimpleNamespace
+    from radvlm_amd.llava.model import LlavaConfig, LlavaLlamaForCausalLM
+    g, meta, images = _golden(golden_dir, "toy_e2e")
+    model = LlavaLlamaForCausalLM(LlavaConfig(geometry=GEOMETRIES["toy"], freeze_lm=True, train_embed_tokens=True), device="cuda:0", init="portable")
+    eng = model.engine
+    assert eng.lm.names()[0] == "model.embed_tokens.weight" and "lm_head.weight" not in eng.lm.offsets and "lm_head.weight" in eng.base.offsets
+    rows = torch.randn(2, 256).to(torch.bfloat16)
+    torch.save({"model.embed_tokens.weight": rows, "model.mm_projector.0.bias": torch.zeros(256)}, tmp_path / "pre.bin")
+    tok = Tok()
+    args = SimpleNamespace(mm_use_im_patch_token=False, mm_use_im_start_end=True, tune_mm_mlp_adapter=True, pretrain_mm_mlp_adapter=str(tmp_path / "pre.bin"))
+    model.initialize_vision_tokenizer(args, tok)
+    assert len(tok) == 1002 and eng.vocab == 1002 and model.config.vocab_size == 1002
+    emb = eng.W("model.embed_tokens.weight")
+    assert emb.shape[0] == 1008 and torch.equal(emb[1000:1002].cpu(), rows) and float(emb[1002:].float().abs().max()) == 0.0
+    head = eng.W("lm_head.weight")
+    assert torch.equal(head[1000], head[:1000].float().mean(0).to(torch.bfloat16))
+    ids = g["input_ids"].copy()
+    ids[0, 1], ids[0, 2] = 1000, 1001
+    head_before, layer_before = head.clone(), eng.W("model.layers.0.mlp.down_proj.weight").clone()
+    loss = float(eng.forward(ids, g["attention_mask"], g["labels"], images))
+    eng.backward()
+    ge = eng.G("model.embed_tokens.weight").float()
+    assert np.isfinite(loss) and float(ge[1000:1002].norm()) > 0 and float(ge[1002:].abs().max()) == 0.0
+    eng.optimizer_step(lr=1e-2, max_grad_norm=1.0)
+    torch.cuda.synchronize()
+    assert not torch.equal(eng.W("model.embed_tokens.weight")[1000:1002].cpu(), rows)           # trained
+    assert torch.equal(eng.W("lm_head.weight"), head_before) and torch.equal(eng.W("model.layers.0.mlp.down_proj.weight"), layer_before)
+    with pytest.raises(ValueError, match="train_embed_tokens"):
+        frozen = LlavaLlamaForCausalLM(LlavaConfig(geometry=GEOMETRIES["toy"], freeze_lm=True), device="cuda:0", init="fast")
+        frozen.initialize_vision_tokenizer(SimpleNamespace(mm_use_im_patch_token=False, mm_use_im_start_end=True, tune_mm_mlp_adapter=True,
+                                                           pretrain_mm_mlp_adapter=None), Tok())

@@ -5,9 +5,13 @@ SQ_BUSY_CYCLES --kernel-trace` counter_collection.csv per kernel family:
   wave-cycle split: ACTIVE_INST_ANY / WAIT_INST_ANY / WAIT_ANY over WAVE_CYCLES (disjoint buckets)."""
 import csv
 import json
+import os
 import re
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from radvlm_amd.build_id import kernel_source_sha256  # noqa: E402
 
 path, out = sys.argv[1], sys.argv[2]
 disp = defaultdict(dict)
@@ -29,7 +33,7 @@ for d, c in disp.items():
         fam[k][key] += v
     fam[k]["launches"] += 1
 res = {"source": "rocprofv3 --pmc (own pass, --kernel-trace only) on `python bench.py --steps 1 --warmup 1 --no-cpu-baseline` (b=32), MI355X",
-       "kernels": {}}
+       "kernel_source_sha256": kernel_source_sha256(), "git_commit": sys.argv[3] if len(sys.argv) > 3 else None, "kernels": {}}
 tot = defaultdict(float)
 for k, c in sorted(fam.items(), key=lambda kv: -kv[1]["_ns"]):
     cyc = c["GRBM_GUI_ACTIVE"] / 8.0
