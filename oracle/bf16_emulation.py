@@ -34,6 +34,15 @@ BF16 = torch.bfloat16
 LOG2E = 1.4426950408889634
 
 
+TRACE = None     # tools/bf16_flip_trace.py sets a dict here to collect every stored tensor by name (diagnostics only)
+
+
+def _t(name, x):
+    if TRACE is not None:
+        TRACE[name] = x.detach().clone()
+    return x
+
+
 def bf16_round(x):
     return x.to(BF16).to(torch.float32)
 
@@ -95,20 +104,24 @@ def decoder_layer(x, P, pre, l, lens, cos, sin, eps, rnd):
     heads, kvh = l["heads"], l.get("kv_heads", l["heads"])
     hd = d // heads
     bias = lambda n: P.get(pre + f"self_attn.{n}.bias")
-    h1 = rmsnorm(x, P[pre + "input_layernorm.weight"], eps, rnd)
+    _t(pre + "x", x)
+    h1 = _t(pre + "h1", rmsnorm(x, P[pre + "input_layernorm.weight"], eps, rnd))
     q = rnd(F.linear(h1, P[pre + "self_attn.q_proj.weight"], bias("q_proj"))).view(b, S, heads, hd).transpose(1, 2)
     k = rnd(F.linear(h1, P[pre + "self_attn.k_proj.weight"], bias("k_proj"))).view(b, S, kvh, hd).transpose(1, 2)
     v = rnd(F.linear(h1, P[pre + "self_attn.v_proj.weight"], bias("v_proj"))).view(b, S, kvh, hd).transpose(1, 2)
+    _t(pre + "v", v.transpose(1, 2).reshape(b, S, -1))
     q, k = rope(q, cos, sin, rnd), rope(k, cos, sin, rnd)
+    _t(pre + "q_roped", q.transpose(1, 2).reshape(b, S, -1)), _t(pre + "k_roped", k.transpose(1, 2).reshape(b, S, -1))
     if kvh != heads:
         k = k.repeat_interleave(heads // kvh, dim=1)
         v = v.repeat_interleave(heads // kvh, dim=1)
-    a = attention(q, k, v, lens, True, 1.0 / math.sqrt(hd), rnd).transpose(1, 2).reshape(b, S, d)
-    x_mid = rnd(F.linear(a, P[pre + "self_attn.o_proj.weight"]) + x)
-    h2 = rmsnorm(x_mid, P[pre + "post_attention_layernorm.weight"], eps, rnd)
+    a = _t(pre + "attn", attention(q, k, v, lens, True, 1.0 / math.sqrt(hd), rnd).transpose(1, 2).reshape(b, S, d))
+    x_mid = _t(pre + "x_mid", rnd(F.linear(a, P[pre + "self_attn.o_proj.weight"]) + x))
+    h2 = _t(pre + "h2", rmsnorm(x_mid, P[pre + "post_attention_layernorm.weight"], eps, rnd))
     g = rnd(F.linear(h2, P[pre + "mlp.gate_proj.weight"]))
     u = rnd(F.linear(h2, P[pre + "mlp.up_proj.weight"]))
-    act = rnd(rnd(g * torch.sigmoid(g)) * u)
+    _t(pre + "gu", torch.cat((g, u), -1))
+    act = _t(pre + "act", rnd(rnd(g * torch.sigmoid(g)) * u))
     return rnd(F.linear(act, P[pre + "mlp.down_proj.weight"]) + x_mid)
 
 
@@ -123,7 +136,8 @@ def llama_forward(P, geo, embeds, lens, rnd):
     x = embeds
     for i in range(l["layers"]):
         x = decoder_layer(x, P, f"model.layers.{i}.", l, lens, cos, sin, eps, rnd)
-    x = rmsnorm(x, P["model.norm.weight"], eps, rnd)
+    _t("x_last", x)
+    x = _t("hN", rmsnorm(x, P["model.norm.weight"], eps, rnd))
     raw = F.linear(x, P["lm_head.weight"])       # fp32 accumulators of the lm_head GEMM (what the engine hands out as .logits)
     return rnd(raw), raw
 
@@ -163,8 +177,10 @@ def vision_tower(P, geo, pixels, rnd, fused_act=True):
 
 
 def mm_projector(P, x, rnd):
-    z = rnd(F.linear(x, P["model.mm_projector.0.weight"], P["model.mm_projector.0.bias"]))
-    return rnd(F.linear(rnd(F.gelu(z)), P["model.mm_projector.2.weight"], P["model.mm_projector.2.bias"]))
+    _t("f0", x)
+    z = _t("z1", rnd(F.linear(x, P["model.mm_projector.0.weight"], P["model.mm_projector.0.bias"])))
+    a1 = _t("a1", rnd(F.gelu(z)))
+    return _t("proj", rnd(F.linear(a1, P["model.mm_projector.2.weight"], P["model.mm_projector.2.bias"])))
 
 
 def llava_forward(P, geo, input_ids, attention_mask, labels, images, image_sizes=None, cfg=None, emulate=True, tower_tunable=False):

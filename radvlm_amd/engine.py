@@ -111,12 +111,13 @@ class LlavaEngine:
                 fast_random_init_(st, self.l["d"], seed + k)
         if self.lora and init in ("portable", "fast"):
             # the projector and the frozen base keep the names (hence values) of the full model; adapters: peft init
+            ga = torch.Generator(device=self.device).manual_seed(seed + 7919)      # seeded: two runs of one command start identically
             for n in self.lm.names():
                 if n.endswith("lora_B.weight"):
                     self.lm.view(n).zero_()
                 elif n.endswith("lora_A.weight") and init == "fast":
                     bound = 1.0 / math.sqrt(self.lm.shapes[n][1])   # kaiming_uniform(a=sqrt(5)) of peft's lora_A
-                    self.lm.view(n).copy_((torch.rand(self.lm.shapes[n], device=self.device) * 2 - 1) * bound)
+                    self.lm.view(n).copy_((torch.rand(self.lm.shapes[n], device=self.device, generator=ga) * 2 - 1) * bound)
         self.lora_step = 0
         self._patch_w = None
         self._rope = {}

@@ -43,6 +43,10 @@ def run_smoke():
     d32, d16 = abs(float(loss) - float(ref_loss)), abs(float(loss) - float(emu_loss))
     print(f"smoke: loss {float(loss):.5f} (oracle fp32 {float(ref_loss):.5f}, bf16-emulated {float(emu_loss):.5f}); logits rel-inf err "
           f"{err16:.3e} vs the bf16-emulated oracle, {err32:.3e} vs fp32 (emulated-vs-fp32 floor {rel(emu_logits[m], ref_logits[m]):.3e})")
-    assert d16 < 1e-3 and err16 < 1e-3, (d16, err16)
+    floor = rel(emu_logits[m], ref_logits[m])
+    # loss at the contract's 1e-3 against the emulation; logits: two bf16 runs agree to within the quantisation floor (a single
+    # summation-order flip cascades through the rows it touches, tests/test_e2e_gpu.py::test_bf16_emulated_parity), and the engine
+    # is as close to fp32 as the emulation is
+    assert d16 < 1e-3 and err16 <= floor and err32 <= 1.1 * floor, (d16, err16, err32, floor)
     assert d32 < 5e-3 and err32 < 1.5e-2, (d32, err32)
     assert bool(torch.isfinite(eng.lm.flat.float()).all())

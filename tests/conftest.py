@@ -18,3 +18,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def record_measurement(test, **values):
+    """Append the measured parity figures of a GPU test to gpurun_out/parity_measured.jsonl (so that gates can be stated as a small
+    multiple of what was measured, and DESIGN.md can quote them)."""
+    import json
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "parity_measured.jsonl"), "a") as f:
+        f.write(json.dumps({"test": test, **values}) + "\n")

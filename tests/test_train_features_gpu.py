@@ -165,9 +165,10 @@ def test_lora_run_saves_the_reference_files_and_resumes(tmp_path):
         assert sorted(nl) == ["base_model.model.model.mm_projector." + k for k in ("0.bias", "0.weight", "2.bias", "2.weight")]
         cfg = json.load(open(tmp_path / "a" / "adapter_config.json"))
         assert cfg["r"] == 8 and cfg["lora_alpha"] == 16 and cfg["peft_type"] == "LORA" and "q_proj" in cfg["target_modules"]
-        # second run: 2 steps, then a restart of the same command with max_steps 4 resumes from checkpoint-2
-        train(argv=_train_args(tmp_path, data, common + ["--max_steps", "2", "--output_dir", str(tmp_path / "b")]), tokenizer=Tok())
-        assert "checkpoint-2" in os.listdir(tmp_path / "b")
+        # a restart of the same command in a directory that holds checkpoint-2 (as if the job had died after step 2) resumes there
+        import shutil
+        os.makedirs(tmp_path / "b")
+        shutil.copytree(tmp_path / "a" / "checkpoint-2", tmp_path / "b" / "checkpoint-2")
         st = train(argv=_train_args(tmp_path, data, common + ["--max_steps", "4", "--output_dir", str(tmp_path / "b")]), tokenizer=Tok())
         assert [r["step"] for r in st["log_history"]] == [1, 2, 3, 4]
         ad2 = torch.load(tmp_path / "b" / "adapter_model.bin", map_location="cpu", weights_only=True)
