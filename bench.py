@@ -130,6 +130,7 @@ class GemmTimer:
     def __init__(self, ops):
         self.ops = ops
         self.orig_nt, self.orig = ops.gemm_nt, ops.gemm
+        self.orig_fused = (ops.gemm_rope, ops.gemm_swiglu_fwd, ops.gemm_swiglu_bwd)
         self.records = []
         self.depth = 0
 
@@ -148,7 +149,7 @@ class GemmTimer:
         out = fn(*args, **kw)
         e1.record()
         # algorithmic bytes of the launch: every operand read once, the output written once
-        abytes += out.numel() * out.element_size()
+        abytes += sum(o.numel() * o.element_size() for o in (out if isinstance(out, tuple) else (out,)))
         for k in ("residual", "bias", "a2", "b2"):
             t = kw.get(k)
             if t is not None:
@@ -166,11 +167,21 @@ class GemmTimer:
             k, m = a.shape if ta else a.shape[::-1]
             n = b.shape[1] if tb else b.shape[0]
             return self._timed(self.orig, 2.0 * m * n * k, nbytes(a) + nbytes(b), a, b, ta=ta, tb=tb, **kw)
+        def rope(a, b, *args, **kw):
+            return self._timed(self.orig_fused[0], 2.0 * a.shape[0] * b.shape[0] * a.shape[1], nbytes(a) + nbytes(b), a, b, *args, **kw)
+
+        def sw_fwd(a, wgu, F, *args, **kw):      # algorithmic bytes: reads x and [gate; up], writes gate|up and act
+            return self._timed(self.orig_fused[1], 2.0 * a.shape[0] * 2 * F * a.shape[1], nbytes(a) + nbytes(wgu) + a.shape[0] * F * 2, a, wgu, F, *args, **kw)
+
+        def sw_bwd(dy, wd, gu, F, *args, **kw):  # reads dy, W_down and gate|up, writes d(gate|up)
+            return self._timed(self.orig_fused[2], 2.0 * dy.shape[0] * F * dy.shape[1], nbytes(dy) + nbytes(wd) + nbytes(gu), dy, wd, gu, F, *args, **kw)
         self.ops.gemm_nt, self.ops.gemm = nt, gen
+        self.ops.gemm_rope, self.ops.gemm_swiglu_fwd, self.ops.gemm_swiglu_bwd = rope, sw_fwd, sw_bwd
         return self
 
     def __exit__(self, *exc):
         self.ops.gemm_nt, self.ops.gemm = self.orig_nt, self.orig
+        self.ops.gemm_rope, self.ops.gemm_swiglu_fwd, self.ops.gemm_swiglu_bwd = self.orig_fused
 
     def summary(self):
         torch.cuda.synchronize()

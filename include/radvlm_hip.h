@@ -58,6 +58,30 @@ int rv_gemm_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void
                     const void* residual, int64_t ldr, int M, int N, int K, int trans_a, int trans_b, float alpha, int act,
                     int out_f32, int res_f32, const void* A2, int64_t lda2, const void* B2, int64_t ldb2, int K2,
                     void* workspace, int64_t workspace_bytes, const void* zeros16, void* stream);
+/* ---- GEMMs with a fused elementwise epilogue (HBM passes removed from the decoder layer) ----------------------------------
+ * Each runs on the 256x256-tile kernel when the output is large enough for it and otherwise performs the unfused sequence itself
+ * (GEMM, then the elementwise kernel) -- bit-identical results either way: the fused epilogues round where the unfused path stored.
+ *
+ * rv_gemm_rope_bf16: C[M,N] = A[M,K] B[N,K]^T + bias, then rotary embedding on the first rope_heads heads of hd columns each
+ *   (q heads followed by k heads of the fused q|k|v projection; the v columns pass through):
+ *   LlamaAttention q_proj/k_proj/v_proj + apply_rotary_pos_emb, modeling_llama.py:332-338 and :167-198 (Qwen2: with q/k/v bias).
+ *   cos_sin: fp32 [positions, hd/2, 2] (LlamaRotaryEmbedding.forward :123-139, rounded through bf16 by the caller);
+ *   position of token row m: positions[m], or m % S when positions is NULL (training: position_ids = arange(S), llava_arch.py:534-545).
+ *   The B rows of a tile are staged in an order that puts the rotation partners (e, e + hd/2) into one lane.  hd 64 or 128 fused. */
+int rv_gemm_rope_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias, int M, int N, int K,
+                      const float* cos_sin, const int32_t* positions, int S, int rope_heads, int hd, void* workspace,
+                      int64_t workspace_bytes, const void* zeros16, void* stream);
+/* rv_gemm_swiglu_fwd_bf16: LlamaMLP's gate/up projections and activation in one launch (modeling_llama.py:226):
+ *   GU[M, 2F] = A[M,K] [Wgate; Wup][2F,K]^T (kept for backward), ACT[M,F] = silu(GU[:, :F]) * GU[:, F:].  Wgu = the stacked [2F, K]
+ *   weight (gate rows then up rows); a tile holds gate and up of the same 128 features, so the product is lane-local. */
+int rv_gemm_swiglu_fwd_bf16(const void* A, int64_t lda, const void* Wgu, int64_t ldb, void* GU, int64_t ldgu, void* ACT, int64_t ldact,
+                            int M, int F, int K, void* workspace, int64_t workspace_bytes, const void* zeros16, void* stream);
+/* rv_gemm_swiglu_bwd_bf16: backward of the same through down_proj's input gradient: dGU[M, 2F] = swiglu'(GU) * (dY[M,K] Wd[K,F])
+ *   with Wd = down_proj.weight stored [K = hidden, F] (read contraction-major, in place); d(act) never reaches memory.
+ *   dact_scratch [M, F] is only used by the unfused fallback (may be NULL when the fused form is certain to run). */
+int rv_gemm_swiglu_bwd_bf16(const void* dY, int64_t ldy, const void* Wd, int64_t ldw, const void* GU, int64_t ldgu, void* dGU, int64_t lddgu,
+                            void* dact_scratch, int64_t ld_dact, int M, int F, int K, void* workspace, int64_t workspace_bytes,
+                            const void* zeros16, void* stream);
 /* Measurement hook (A/B tools and tests only; the product path never calls it): 0 = automatic tile selection (default),
  * 1 = 128x128 tile kernel, 2 = 256x256 tile kernel, 20 / 21 = tail split off / on.  Process-wide. */
 int rv_gemm_select_kernel(int which);
@@ -143,12 +167,38 @@ int rv_attn_bwd(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const 
 int rv_attn_fwd_gqa(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* vT, void* out, int64_t ld_o,
                     float* lse, const int32_t* lens, const int32_t* cu_rows, int B, int H, int H_kv, int S, int S_pad, int hd,
                     int causal, float scale, const void* zeros16, void* stream);
+/* Forward for head_dim 128 on the operands as they lie in memory: v is the token-major [(b*S+s), H_kv*hd] view like k (no V^T copy).
+ * Every tile is staged once into an LDS image that serves row reads (contraction over head_dim) and hardware-transposed column
+ * reads (contraction over the tile's keys, ds_read_b64_tr_b16).  Same semantics, masks and packed-batch conventions as
+ * rv_attn_fwd_gqa. */
+int rv_attn_fwd_nat(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v, void* out, int64_t ld_o,
+                    float* lse, const int32_t* lens, const int32_t* cu_rows, int B, int H, int H_kv, int S, int S_pad, int hd, int causal,
+                    float scale, const void* zeros16, void* stream);
 int rv_attn_bwd_gqa(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v, const void* o,
                     int64_t ld_o, const void* dout, int64_t ld_do, const void* qT, const void* kT, const void* doT,
                     const float* lse, float* delta, void* dq, int64_t ld_dq, void* dk, int64_t ld_dk, void* dv,
                     int64_t ld_dv, const int32_t* lens, const int32_t* cu_rows, int total_rows, int B, int H, int H_kv, int S,
                     int S_pad, int hd, int causal, float scale, void* workspace, int64_t workspace_bytes, const void* zeros16,
                     void* stream);
+/* The same with the adjoint of the rotary embedding folded into the dQ / dK epilogues (the backward of apply_rotary_pos_emb,
+ * modeling_llama.py:167-198, on q and k that are stored rotated): dq and dk come out as gradients of the UN-rotated projections,
+ * no separate pass over d(q|k|v).  rope_cos_sin: fp32 [positions, hd/2, 2] (NULL = plain rv_attn_bwd_gqa); position of a token row =
+ * rope_positions[row] (required for packed batches) or its index inside the sample. */
+int rv_attn_bwd_gqa_rope(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v, const void* o,
+                         int64_t ld_o, const void* dout, int64_t ld_do, const void* qT, const void* kT, const void* doT,
+                         const float* lse, float* delta, void* dq, int64_t ld_dq, void* dk, int64_t ld_dk, void* dv,
+                         int64_t ld_dv, const int32_t* lens, const int32_t* cu_rows, int total_rows, int B, int H, int H_kv, int S,
+                         int S_pad, int hd, int causal, float scale, void* workspace, int64_t workspace_bytes,
+                         const float* rope_cos_sin, const int32_t* rope_positions, const void* zeros16, void* stream);
+
+/* Backward for head_dim 128 on the operands as they lie in memory (no q^T / k^T / dO^T copies: every staged tile serves row reads and
+ * hardware-transposed column reads, see rv_attn_fwd_nat), with the optional rotary-embedding adjoint of rv_attn_bwd_gqa_rope.
+ * delta [B,H,S_pad] fp32 is scratch written by the dQ pass (rowsum(dO * O)) and read by the dK/dV pass. */
+int rv_attn_bwd_nat(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v, const void* o, int64_t ld_o,
+                    const void* dout, int64_t ld_do, const float* lse, float* delta, void* dq, int64_t ld_dq, void* dk, int64_t ld_dk,
+                    void* dv, int64_t ld_dv, const int32_t* lens, const int32_t* cu_rows, int total_rows, int B, int H, int H_kv, int S,
+                    int S_pad, int hd, int causal, float scale, void* workspace, int64_t workspace_bytes, const float* rope_cos_sin,
+                    const int32_t* rope_positions, const void* zeros16, void* stream);
 
 /* rv_transpose_bf16 for packed batches: batch b0 reads rows [cu_rows[b0], cu_rows[b0+1]) of `in` (R_max = longest). */
 int rv_transpose_bf16_varlen(const void* in, int64_t in_ld, const int32_t* cu_rows, int64_t in_bs1, void* out, int64_t out_ld,

@@ -30,7 +30,29 @@ struct AttnParams {
     int kdiv, qrep;  // dK/dV pass: block head h reads k/v head h / kdiv and walks query heads [h*qrep, (h+1)*qrep)
     int Hkv, nrep;   // grouped-query attention: query head h reads key/value head h / nrep (repeat_kv, modeling_llama.py:201-210)
     float scale;
+    // backward only: adjoint of the rotary embedding applied to dQ / dK in the epilogue (q, k are stored rotated; the projection
+    // weights see un-rotated gradients).  cs = fp32 [positions, HD/2, 2]; position of row r of sample b: rope_pos[rb + r] or r.
+    const float* rope_cs; const int* rope_pos;
+    int rope_dk;      // the dK/dV pass rotates dK itself (0 when per-query-head partials are summed first: group_sum_heads_kernel rotates)
 };
+
+// Inverse rotation of one lane's accumulator column set: v[db] holds dimensions 16 db + 4 g + r of one row, partners are db and
+// db + DB/2.  Rounds through bf16 first (the unfused path stored the gradient before rotating it: same rounding points).
+template <int DB>
+DEVINL void unrope(f32x4 (&v)[DB], const float* cs_row, int g) {
+#pragma unroll
+    for (int db = 0; db < DB / 2; ++db) {
+        const float* c = cs_row + (16 * db + 4 * g) * 2;
+        const f32x4 t0 = *(const f32x4*)c, t1 = *(const f32x4*)(c + 4);
+        const float co[4] = {t0[0], t0[2], t1[0], t1[2]}, si[4] = {t0[1], t0[3], t1[1], t1[3]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = bf2f(f2bf(v[db][r])), b = bf2f(f2bf(v[db + DB / 2][r]));
+            v[db][r] = a * co[r] + b * si[r];
+            v[db + DB / 2][r] = b * co[r] - a * si[r];
+        }
+    }
+}
 
 template <int ROW_BYTES> DEVINL int swz(int r) { return ROW_BYTES == 128 ? ((r >> 1) & 7) : (r & 15); }
 
@@ -247,6 +269,530 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
     }
 }
 
+
+// ================================================================================================ natural-layout kernels (HD = 128)
+// No transposed operand copies: every tile is staged as it lies in memory ([64 token rows][128 head dims], 256-byte rows) into ONE
+// LDS image that serves both kinds of MFMA operand reads --
+//   row reads   (contraction over the head dimension): ds_read_b128 of 8 consecutive dims of one row;
+//   column reads (contraction over the tile's token rows): ds_read_b64_tr_b16 pairs, which hand lane (g, i) dimension 16 db + i of the
+//                rows 32 p + 4 g + {0..3} and 32 p + 16 + 4 g + {0..3} -- exactly the contraction order kappa(g, j) in which a score
+//                tile sits in the accumulators, so P / dS feed the next MFMA chain straight from registers as before.
+// Swizzle: 16-byte chunk ch of row r is stored at chunk ch ^ ((r & 7) << 1).  Row reads: a 16-lane service group sees 8 rows x 2
+// chunk parities -> 16 distinct 16-byte slots; column reads: the 8 rows of a 32-lane half land on 8 distinct 32-byte granules.
+typedef __attribute__((ext_vector_type(4))) short s16x4n;
+struct TFrag { s16x4n t0, t1; };
+DEVINL int nswz(int r) { return (r & 7) << 1; }
+DEVINL unsigned lds_off(const char* a) { return (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)a; }
+
+template <int NROWS, int NW>
+DEVINL void stage_nat(const bf16* src, long row_stride, int valid_rows, const bf16* zeros, char* lds, int wid, int lane) {
+    constexpr int NI = NROWS * 16 / 64;
+    static_assert(NI % NW == 0, "tile must split evenly over the block's waves");
+#pragma unroll
+    for (int i = 0; i < NI / NW; ++i) {
+        const int it = i * NW + wid;
+        const int c = it * 64 + lane;
+        const int r = c >> 4, pch = c & 15;
+        const int lc = pch ^ nswz(r);
+        const bf16* g = (r < valid_rows) ? (src + (long)r * row_stride + lc * 8) : zeros;
+        glds16(g, lds + it * 1024);
+    }
+}
+DEVINL void rdrow_asm(bf16x8& dst, const char* tile, int row, int chunk) {
+    const unsigned o = lds_off(tile + row * 256 + ((chunk ^ nswz(row)) << 4));
+    asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(o) : "memory");
+}
+// column-read fragment of dims [16 db, 16 db + 16) over rows kappa(g, 0..7) of the 32-row step p
+DEVINL void rdcol_asm(TFrag& f, const char* tile, int p, int db, int lane) {
+    const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int r1 = 32 * p + 4 * g + qq;
+    const unsigned o = lds_off(tile + r1 * 256 + (((2 * db + (pp >> 1)) ^ nswz(r1)) << 4) + ((pp & 1) << 3));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.t0) : "v"(o) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(f.t1) : "v"(o) : "memory");     // rows + 16: same swizzle term
+}
+DEVINL bf16x8 tf_get(const TFrag& f) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8n;
+    const s16x8n r = {f.t0[0], f.t0[1], f.t0[2], f.t0[3], f.t1[0], f.t1[1], f.t1[2], f.t1[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+template <int LEFT> DEVINL void tf_wait4(TFrag (&f)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(f[0].t0), "+v"(f[0].t1), "+v"(f[1].t0), "+v"(f[1].t1), "+v"(f[2].t0), "+v"(f[2].t1), "+v"(f[3].t0), "+v"(f[3].t1)
+                 : "i"(LEFT) : "memory");
+}
+
+// ------------------------------------------------------------------------------------------------ forward (natural V)
+// Softmax arithmetic per score: one v_max, one v_fma (s * scale*log2e - m) and one v_exp; the causal / key-padding mask is only
+// evaluated on the tiles that touch the diagonal or the end of the sample.
+template <bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
+    constexpr int HD = 128, KS = 4, DB = 8, TILE = 64 * 256, STAGE = 2 * TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wid = wave_id(), lane = lane_id(), g = lane >> 4, c = lane & 15;
+    const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const long rb = P.cu ? (long)P.cu[b] : (long)b * P.S;
+    const int S = P.cu ? P.cu[b + 1] - P.cu[b] : P.S, q0 = qblk * 128 + wid * 32;
+    if (qblk * 128 >= S) return;
+    const int len = (P.lens && !P.cu) ? P.lens[b] : S;
+    const float sl2 = P.scale * LOG2E;
+
+    bf16x8 qf[2][KS];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        const int row = min(q0 + qs * 16 + c, S - 1);
+        const bf16* p = P.q + (rb + row) * P.ld_q + h * HD + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[qs][ks] = *(const bf16x8*)(p + ks * 32);
+    }
+    const int kv_end = CAUSAL ? min(len, qblk * 128 + 128) : len;
+    const int ntiles = (kv_end + 63) >> 6;
+    const int hk = h / P.nrep;
+    const bf16* kbase = P.k + rb * P.ld_k + hk * HD;
+    const bf16* vbase = P.v + rb * P.ld_v + hk * HD;
+
+    float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+    f32x4 o[2][DB];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) o[qs][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    stage_nat<64, 4>(kbase, P.ld_k, S, P.zeros, smem, wid, lane);
+    stage_nat<64, 4>(vbase, P.ld_v, S, P.zeros, smem + TILE, wid, lane);
+
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* Kt = smem + (t & 1) * STAGE;
+        const char* Vt = Kt + TILE;
+        if (t + 1 < ntiles) {
+            char* nx = smem + ((t + 1) & 1) * STAGE;
+            const int kv1 = (t + 1) * 64;
+            stage_nat<64, 4>(kbase + (long)kv1 * P.ld_k, P.ld_k, S - kv1, P.zeros, nx, wid, lane);
+            stage_nat<64, 4>(vbase + (long)kv1 * P.ld_v, P.ld_v, S - kv1, P.zeros, nx + TILE, wid, lane);
+        }
+        const int kv0 = t * 64;
+        if (CAUSAL && kv0 > q0 + 31) continue;  // every key of this tile is in the future of this wave's rows
+
+        f32x4 s[2][4];
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) s[qs][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {   // S^T = K Q^T
+            bf16x8 kq[3][KS];
+            auto issue_k = [&](int kb, bf16x8 (&dst)[KS]) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) rdrow_asm(dst[ks], Kt, kb * 16 + c, ks * 4 + g);
+            };
+            issue_k(0, kq[0]);
+            issue_k(1, kq[1]);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                if (kb + 2 < 4) issue_k(kb + 2, kq[(kb + 2) % 3]);
+                if (kb < 2) lds_wait<KS, 2 * KS>(kq[kb % 3]);
+                else if (kb == 2) lds_wait<KS, KS>(kq[kb % 3]);
+                else lds_wait<KS, 0>(kq[kb % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int qs = 0; qs < 2; ++qs) s[qs][kb] = mfma16(kq[kb % 3][ks], qf[qs][ks], s[qs][kb]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // V column fragments of the first two batches are fetched behind the softmax arithmetic
+        TFrag vq[3][4];
+        constexpr int NB = 2 * DB / 4;
+        auto issue_v = [&](int bi, TFrag (&dst)[4]) {
+            const int kp = bi / (DB / 4), db0 = (bi % (DB / 4)) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rdcol_asm(dst[u], Vt, kp, db0 + u, lane);
+        };
+        issue_v(0, vq[0]);
+        issue_v(1, vq[1]);
+        // lane holds S^T[key = kv0 + 16kb + 4g + r][q = q0 + 16qs + c]
+        const bool edge = (kv0 + 64 > len) || (CAUSAL && kv0 + 63 > q0);     // wave-uniform: some score of this tile may be masked
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            if (edge) {
+                const int qidx = q0 + qs * 16 + c;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kidx = kv0 + kb * 16 + 4 * g + r;
+                        const bool ok = (kidx < len) && (!CAUSAL || kidx <= qidx);
+                        s[qs][kb][r] = ok ? s[qs][kb][r] : -INFINITY;
+                    }
+            }
+            float mx = fmaxf(fmaxf(s[qs][0][0], s[qs][0][1]), fmaxf(s[qs][0][2], s[qs][0][3]));
+#pragma unroll
+            for (int kb = 1; kb < 4; ++kb) mx = fmaxf(mx, fmaxf(fmaxf(s[qs][kb][0], s[qs][kb][1]), fmaxf(s[qs][kb][2], s[qs][kb][3])));
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(m[qs], mx * sl2);        // scale > 0: the maximum commutes with the scaling
+            const float alpha = fexp2(m[qs] - mnew);
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = fexp2(__builtin_fmaf(s[qs][kb][r], sl2, -mnew));
+                    s[qs][kb][r] = p;
+                    rs += p;
+                }
+            l[qs] = l[qs] * alpha + rs;
+            m[qs] = mnew;
+#pragma unroll
+            for (int db = 0; db < DB; ++db) o[qs][db] *= alpha;
+        }
+        // O^T[d][q] += V^T[d][key] P^T[key][q]
+        {
+            bf16x8 pf[2][2];
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs) pf[kp][qs] = pack8(s[qs][2 * kp], s[qs][2 * kp + 1]);
+#pragma unroll
+            for (int bi = 0; bi < NB; ++bi) {
+                if (bi + 2 < NB) issue_v(bi + 2, vq[(bi + 2) % 3]);
+                if (bi + 2 < NB) tf_wait4<15>(vq[bi % 3]);           // 16 younger reads in flight (the 4-bit counter saturates at 15)
+                else if (bi + 1 < NB) tf_wait4<8>(vq[bi % 3]);
+                else tf_wait4<0>(vq[bi % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                const int kp = bi / (DB / 4), db0 = (bi % (DB / 4)) * 4;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bf16x8 vf = tf_get(vq[bi % 3][u]);
+#pragma unroll
+                    for (int qs = 0; qs < 2; ++qs) o[qs][db0 + u] = mfma16(vf, pf[kp][qs], o[qs][db0 + u]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        float lt = l[qs];
+        lt += __shfl_xor(lt, 16, 64);
+        lt += __shfl_xor(lt, 32, 64);
+        const int qidx = q0 + qs * 16 + c;
+        if (qidx >= S) continue;
+        const float inv = 1.f / lt;
+        bf16* op = P.out + (rb + qidx) * P.ld_o + h * HD + 4 * g;
+#pragma unroll
+        for (int db = 0; db < DB; ++db) {
+            const f32x4 v = o[qs][db] * inv;
+            *(bf16x4*)(op + db * 16) = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        }
+        if (g == 0 && P.lse) P.lse[(long)(b * P.H + h) * P.S_pad + qidx] = (m[qs] + __builtin_amdgcn_logf(lt)) * LN2;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------ backward dQ (natural K, V)
+// 8 waves x 32 query rows per block; per 64-key tile: S^T = K Q^T and dP^T = V dO^T from row reads, dQ^T += K^T dS^T from column
+// reads of the SAME K image (no K^T copy).  p = exp2(s * scale*log2e - lse*log2e) is one fma + one exp per score.
+template <bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dq_nat_kernel(AttnParams P) {
+    constexpr int HD = 128, KS = 4, DB = 8, TILE = 64 * 256, STAGE = 2 * TILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wid = wave_id(), lane = lane_id(), g = lane >> 4, c = lane & 15;
+    const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const long rb = P.cu ? (long)P.cu[b] : (long)b * P.S;
+    const int S = P.cu ? P.cu[b + 1] - P.cu[b] : P.S, q0 = qblk * (32 * NW) + wid * 32;
+    if (qblk * (32 * NW) >= S) return;
+    const int len = (P.lens && !P.cu) ? P.lens[b] : S;
+    const float sl2 = P.scale * LOG2E;
+
+    bf16x8 qf[2][KS], dof[2][KS];
+    float lse2[2], dl[2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        const int row = min(q0 + qs * 16 + c, S - 1);
+        const bf16* p = P.q + (rb + row) * P.ld_q + h * HD + g * 8;
+        const bf16* d = P.dout + (rb + row) * P.ld_do + h * HD + g * 8;
+        const bf16* op = P.o + (rb + row) * P.ld_o + h * HD + g * 8;
+        float dsum = 0.f;   // delta = rowsum(dO * O), fused here (this lane owns 8 * KS of the row's HD products)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[qs][ks] = *(const bf16x8*)(p + ks * 32);
+            dof[qs][ks] = *(const bf16x8*)(d + ks * 32);
+            const bf16x8 ov = *(const bf16x8*)(op + ks * 32);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dsum += bf2f(ov[j]) * bf2f(dof[qs][ks][j]);
+        }
+        dsum += __shfl_xor(dsum, 16, 64);
+        dsum += __shfl_xor(dsum, 32, 64);
+        lse2[qs] = P.lse[(long)(b * P.H + h) * P.S_pad + row] * LOG2E;
+        dl[qs] = dsum;
+        if (g == 0 && q0 + qs * 16 + c < S) P.delta[(long)(b * P.H + h) * P.S_pad + row] = dsum;   // for the dK/dV pass
+    }
+    const int kv_end = CAUSAL ? min(len, (qblk + 1) * (32 * NW)) : len;
+    const int ntiles = (kv_end + 63) >> 6;
+    const int hk = h / P.nrep;
+    const bf16* kbase = P.k + rb * P.ld_k + hk * HD;
+    const bf16* vbase = P.v + rb * P.ld_v + hk * HD;
+
+    f32x4 dq[2][DB];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+        for (int db = 0; db < DB; ++db) dq[qs][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    stage_nat<64, NW>(kbase, P.ld_k, S, P.zeros, smem, wid, lane);
+    stage_nat<64, NW>(vbase, P.ld_v, S, P.zeros, smem + TILE, wid, lane);
+
+    for (int t = 0; t < ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* Kt = smem + (t & 1) * STAGE;
+        const char* Vt = Kt + TILE;
+        if (t + 1 < ntiles) {
+            char* nx = smem + ((t + 1) & 1) * STAGE;
+            const int kv1 = (t + 1) * 64;
+            stage_nat<64, NW>(kbase + (long)kv1 * P.ld_k, P.ld_k, S - kv1, P.zeros, nx, wid, lane);
+            stage_nat<64, NW>(vbase + (long)kv1 * P.ld_v, P.ld_v, S - kv1, P.zeros, nx + TILE, wid, lane);
+        }
+        const int kv0 = t * 64;
+        if (CAUSAL && kv0 > q0 + 31) continue;
+
+        f32x4 s[2][4], dp[2][4];
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) { s[qs][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qs][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        {   // row fragments of K and V in batches of two k-steps: batch i + 1 is in flight while batch i's MFMAs run
+            bf16x8 kq[2][2], vq[2][2];
+            auto issue = [&](int bi, bf16x8 (&kd)[2], bf16x8 (&vd)[2]) {
+                const int kb = bi >> 1, ks0 = (bi & 1) * 2;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { rdrow_asm(kd[u], Kt, kb * 16 + c, (ks0 + u) * 4 + g); rdrow_asm(vd[u], Vt, kb * 16 + c, (ks0 + u) * 4 + g); }
+            };
+            issue(0, kq[0], vq[0]);
+#pragma unroll
+            for (int bi = 0; bi < 8; ++bi) {
+                if (bi + 1 < 8) issue(bi + 1, kq[(bi + 1) & 1], vq[(bi + 1) & 1]);
+                if (bi + 1 < 8) { lds_wait<2, 4>(kq[bi & 1]); lds_wait<2, 4>(vq[bi & 1]); }
+                else { lds_wait<2, 0>(kq[bi & 1]); lds_wait<2, 0>(vq[bi & 1]); }
+                __builtin_amdgcn_sched_barrier(0);
+                const int kb = bi >> 1, ks0 = (bi & 1) * 2;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int qs = 0; qs < 2; ++qs) {
+                        s[qs][kb] = mfma16(kq[bi & 1][u], qf[qs][ks0 + u], s[qs][kb]);
+                        dp[qs][kb] = mfma16(vq[bi & 1][u], dof[qs][ks0 + u], dp[qs][kb]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the K column fragments of the first dQ batch are fetched behind the elementwise part
+        TFrag kc[4];
+        auto issue_c = [&](int bi) {
+            const int kp = bi / (DB / 4), db0 = (bi % (DB / 4)) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rdcol_asm(kc[u], Kt, kp, db0 + u, lane);
+        };
+        issue_c(0);
+        const bool edge = (kv0 + 64 > len) || (CAUSAL && kv0 + 63 > q0);
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            const int qidx = q0 + qs * 16 + c;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = fexp2(__builtin_fmaf(s[qs][kb][r], sl2, -lse2[qs]));
+                    float ds = p * (dp[qs][kb][r] - dl[qs]);
+                    if (edge) {
+                        const int kidx = kv0 + kb * 16 + 4 * g + r;
+                        ds = ((kidx < len) && (!CAUSAL || kidx <= qidx)) ? ds : 0.f;
+                    }
+                    s[qs][kb][r] = ds;
+                }
+        }
+        constexpr int NB = 2 * DB / 4;
+        bf16x8 dsf[2][2];
+#pragma unroll
+        for (int kp = 0; kp < 2; ++kp)
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) dsf[kp][qs] = pack8(s[qs][2 * kp], s[qs][2 * kp + 1]);
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi) {
+            tf_wait4<0>(kc);
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8 ktf[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ktf[u] = tf_get(kc[u]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (bi + 1 < NB) issue_c(bi + 1);          // the next batch lands behind this batch's MFMAs
+            const int kp = bi / (DB / 4), db0 = (bi % (DB / 4)) * 4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int qs = 0; qs < 2; ++qs) dq[qs][db0 + u] = mfma16(ktf[u], dsf[kp][qs], dq[qs][db0 + u]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+        const int qidx = q0 + qs * 16 + c;
+        if (qidx >= S) continue;
+        bf16* op = P.dq + (rb + qidx) * P.ld_dq + h * HD + 4 * g;
+        f32x4 v[DB];
+#pragma unroll
+        for (int db = 0; db < DB; ++db) v[db] = dq[qs][db] * P.scale;
+        if (P.rope_cs) unrope<DB>(v, P.rope_cs + (long)(P.rope_pos ? P.rope_pos[rb + qidx] : qidx) * HD, g);
+#pragma unroll
+        for (int db = 0; db < DB; ++db) *(bf16x4*)(op + db * 16) = bf16x4{f2bf(v[db][0]), f2bf(v[db][1]), f2bf(v[db][2]), f2bf(v[db][3])};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward dK, dV (natural Q, dO)
+// 8 waves x 16 keys per block; per 64-query tile: S = Q K^T and dP = dO V^T from row reads of the Q / dO images, dV^T += dO^T P and
+// dK^T += Q^T dS from column reads of the SAME images (no Q^T / dO^T copies: half the staging traffic of the transposed-copy form).
+template <bool CAUSAL, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dkv_nat_kernel(AttnParams P) {
+    constexpr int HD = 128, KS = 4, DB = 8, TILE = 64 * 256, STAGE = 2 * TILE + 1024;   // Q | dO | lse, delta
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wid = wave_id(), lane = lane_id(), g = lane >> 4, c = lane & 15;
+    const int kblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    constexpr int KPB = NW * 16;   // keys per block
+    const long rb = P.cu ? (long)P.cu[b] : (long)b * P.S;
+    const int S = P.cu ? P.cu[b + 1] - P.cu[b] : P.S, k0 = kblk * KPB + wid * 16;
+    if (kblk * KPB >= S) return;
+    const int len = (P.lens && !P.cu) ? P.lens[b] : S;
+    const float sl2 = P.scale * LOG2E;
+
+    bf16x8 kf[KS], vf[KS];
+    {
+        const int row = min(k0 + c, S - 1);
+        const bf16* kp = P.k + (rb + row) * P.ld_k + (h / P.kdiv) * HD + g * 8;
+        const bf16* vp = P.v + (rb + row) * P.ld_v + (h / P.kdiv) * HD + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { kf[ks] = *(const bf16x8*)(kp + ks * 32); vf[ks] = *(const bf16x8*)(vp + ks * 32); }
+    }
+    const int q_end = len;  // query rows >= len carry zero dO
+    const int t0 = CAUSAL ? (kblk * KPB) >> 6 : 0;
+    const int t1 = (q_end + 63) >> 6;
+    const int nt = max(t1 - t0, 0);
+    const int n_it = nt * P.qrep;
+
+    f32x4 dv[DB], dk[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) { dv[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    auto stage = [&](int it, char* dst) {
+        const int hq = h * P.qrep + it / nt;
+        const int qt0 = (t0 + it % nt) * 64;
+        const bf16* qbase = P.q + rb * P.ld_q + hq * HD;
+        const bf16* dobase = P.dout + rb * P.ld_do + hq * HD;
+        const float* lsebase = P.lse + (long)(b * P.H + hq) * P.S_pad;
+        const float* dlbase = P.delta + (long)(b * P.H + hq) * P.S_pad;
+        stage_nat<64, NW>(qbase + (long)qt0 * P.ld_q, P.ld_q, S - qt0, P.zeros, dst, wid, lane);
+        stage_nat<64, NW>(dobase + (long)qt0 * P.ld_do, P.ld_do, S - qt0, P.zeros, dst + TILE, wid, lane);
+        if (wid == 0) {   // lse / delta of the tile's 64 query rows ride the same LDS-DMA stream
+            const float* gp = lane < 16 ? lsebase + qt0 + lane * 4 : (lane < 32 ? dlbase + qt0 + (lane - 16) * 4 : (const float*)P.zeros);
+            glds16(gp, dst + 2 * TILE);
+        }
+    };
+    if (n_it > 0) stage(0, smem);
+
+    for (int it = 0; it < n_it; ++it) {
+        const int t = t0 + it % nt;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* Qt = smem + (it & 1) * STAGE;
+        const char* dOt = Qt + TILE;
+        const char* LSt = Qt + 2 * TILE;   // [64 lse | 64 delta] fp32
+        if (it + 1 < n_it) stage(it + 1, smem + ((it + 1) & 1) * STAGE);
+        const int qt0 = t * 64;
+        if (CAUSAL && qt0 + 63 < k0) continue;  // every query of this tile precedes this wave's keys
+        const bool edge = (qt0 + 64 > q_end) || (k0 + 16 > len) || (CAUSAL && qt0 < k0 + 15);
+
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+            // column fragments of this 32-query step (for dV, dK) are fetched first: they are consumed last
+            TFrag dc[2][4], qc[2][4];
+            auto issue_c = [&](int bi, TFrag (&dd)[4], TFrag (&qd)[4]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { rdcol_asm(dd[u], dOt, qp, bi * 4 + u, lane); rdcol_asm(qd[u], Qt, qp, bi * 4 + u, lane); }
+            };
+            f32x4 s[2], dp[2];
+            s[0] = s[1] = dp[0] = dp[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bf16x8 qa[2][KS], da[2][KS];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    rdrow_asm(qa[qq][ks], Qt, (2 * qp + qq) * 16 + c, ks * 4 + g);
+                    rdrow_asm(da[qq][ks], dOt, (2 * qp + qq) * 16 + c, ks * 4 + g);
+                }
+            lds_wait<KS, 2 * KS>(qa[0]); lds_wait<KS, 2 * KS>(da[0]);       // the 8 reads of the second 16-query block stay in flight
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { s[0] = mfma16(qa[0][ks], kf[ks], s[0]); dp[0] = mfma16(da[0][ks], vf[ks], dp[0]); }
+            __builtin_amdgcn_sched_barrier(0);
+            issue_c(0, dc[0], qc[0]);                                        // 16 column reads, consumed after the elementwise part
+            lds_wait<KS, 15>(qa[1]); lds_wait<KS, 15>(da[1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { s[1] = mfma16(qa[1][ks], kf[ks], s[1]); dp[1] = mfma16(da[1][ks], vf[ks], dp[1]); }
+            __builtin_amdgcn_sched_barrier(0);
+            // lane holds S[q = qt0 + 16qb + 4g + r][key = k0 + c]
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int qrow = qt0 + (2 * qp + qq) * 16 + 4 * g;
+                const f32x4 ls = *(const f32x4*)(LSt + (qrow - qt0) * 4);
+                const f32x4 dl = *(const f32x4*)(LSt + 256 + (qrow - qt0) * 4);
+                const int kidx = k0 + c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float p = fexp2(__builtin_fmaf(s[qq][r], sl2, -ls[r] * LOG2E));
+                    if (edge) {
+                        const int qidx = qrow + r;
+                        p = ((kidx < len) && (qidx < q_end) && (!CAUSAL || kidx <= qidx)) ? p : 0.f;
+                    }
+                    s[qq][r] = p;
+                    dp[qq][r] = p * (dp[qq][r] - dl[r]);
+                }
+            }
+            const bf16x8 pf = pack8(s[0], s[1]), dsf = pack8(dp[0], dp[1]);
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi) {
+                if (bi == 0) { issue_c(1, dc[1], qc[1]); tf_wait4<15>(dc[0]); tf_wait4<15>(qc[0]); }
+                else { tf_wait4<0>(dc[1]); tf_wait4<0>(qc[1]); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    dv[bi * 4 + u] = mfma16(tf_get(dc[bi][u]), pf, dv[bi * 4 + u]);
+                    dk[bi * 4 + u] = mfma16(tf_get(qc[bi][u]), dsf, dk[bi * 4 + u]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // lane holds dV^T[d = 16db + 4g + r][key = k0 + c]
+    {
+        const int kidx = k0 + c;
+        if (kidx < S) {
+            bf16* vp = P.dv + (rb + kidx) * P.ld_dv + h * HD + 4 * g;
+            bf16* kp = P.dk + (rb + kidx) * P.ld_dk + h * HD + 4 * g;
+            f32x4 kk[DB];
+#pragma unroll
+            for (int db = 0; db < DB; ++db) kk[db] = dk[db] * P.scale;
+            if (P.rope_cs && P.rope_dk) unrope<DB>(kk, P.rope_cs + (long)(P.rope_pos ? P.rope_pos[rb + kidx] : kidx) * HD, g);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                const f32x4 a = dv[db];
+                *(bf16x4*)(vp + db * 16) = bf16x4{f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3])};
+                *(bf16x4*)(kp + db * 16) = bf16x4{f2bf(kk[db][0]), f2bf(kk[db][1]), f2bf(kk[db][2]), f2bf(kk[db][3])};
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ backward: dQ
 template <int HD, bool CAUSAL, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dq_kernel(AttnParams P) {
@@ -365,11 +911,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dq_kernel(AttnParams
         const int qidx = q0 + qs * 16 + c;
         if (qidx >= S) continue;
         bf16* op = P.dq + (rb + qidx) * P.ld_dq + h * HD + 4 * g;
+        f32x4 v[DB];
 #pragma unroll
-        for (int db = 0; db < DB; ++db) {
-            const f32x4 v = dq[qs][db] * P.scale;
-            *(bf16x4*)(op + db * 16) = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        }
+        for (int db = 0; db < DB; ++db) v[db] = dq[qs][db] * P.scale;
+        if (P.rope_cs) unrope<DB>(v, P.rope_cs + (long)(P.rope_pos ? P.rope_pos[rb + qidx] : qidx) * HD, g);
+#pragma unroll
+        for (int db = 0; db < DB; ++db) *(bf16x4*)(op + db * 16) = bf16x4{f2bf(v[db][0]), f2bf(v[db][1]), f2bf(v[db][2]), f2bf(v[db][3])};
     }
 }
 
@@ -511,32 +1058,50 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dkv_kernel(AttnParam
         if (kidx >= S) continue;
         bf16* vp = P.dv + (rb + kidx) * P.ld_dv + h * HD + 4 * g;
         bf16* kp = P.dk + (rb + kidx) * P.ld_dk + h * HD + 4 * g;
+        f32x4 kk[DB];
+#pragma unroll
+        for (int db = 0; db < DB; ++db) kk[db] = dk[db][kb] * P.scale;
+        if (P.rope_cs && P.rope_dk) unrope<DB>(kk, P.rope_cs + (long)(P.rope_pos ? P.rope_pos[rb + kidx] : kidx) * HD, g);
 #pragma unroll
         for (int db = 0; db < DB; ++db) {
-            const f32x4 a = dv[db][kb], bb = dk[db][kb] * P.scale;
+            const f32x4 a = dv[db][kb];
             *(bf16x4*)(vp + db * 16) = bf16x4{f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3])};
-            *(bf16x4*)(kp + db * 16) = bf16x4{f2bf(bb[0]), f2bf(bb[1]), f2bf(bb[2]), f2bf(bb[3])};
+            *(bf16x4*)(kp + db * 16) = bf16x4{f2bf(kk[db][0]), f2bf(kk[db][1]), f2bf(kk[db][2]), f2bf(kk[db][3])};
         }
     }
 }
 
-// out[m, hk*HD + e] = sum_r tmp[m, (hk*nrep + r)*HD + e]  (fp32 sum of the group's per-query-head dK or dV partials)
-__global__ void group_sum_heads_kernel(const bf16* tmp, long ld_tmp, bf16* out, long ld_out, long rows, int Hkv, int nrep, int hd) {
-    const int per_row = Hkv * hd / 8;
+// out[m, hk*HD + e] = sum_r tmp[m, (hk*nrep + r)*HD + e]  (fp32 sum of the group's per-query-head dK or dV partials); with `cs` the
+// summed dK row is un-rotated too (a thread owns dimensions e .. e+7 and their partners e + hd/2 ..).
+__global__ void group_sum_heads_kernel(const bf16* tmp, long ld_tmp, bf16* out, long ld_out, long rows, int Hkv, int nrep, int hd,
+                                       const float* cs, const int* rope_pos, const int* cu, int S) {
+    const int per_row = Hkv * hd / 16;
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= rows * per_row) return;
     const long m = tid / per_row;
-    const int col = (tid % per_row) * 8, hk = col / hd, e = col % hd;
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int t = tid % per_row, half = hd / 2, hk = t / (half / 8), e = (t % (half / 8)) * 8;
+    float lo[8] = {0, 0, 0, 0, 0, 0, 0, 0}, hi[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int r = 0; r < nrep; ++r) {
-        const bf16x8 v = *(const bf16x8*)(tmp + m * ld_tmp + (long)(hk * nrep + r) * hd + e);
+        const bf16* p = tmp + m * ld_tmp + (long)(hk * nrep + r) * hd + e;
+        const bf16x8 a = *(const bf16x8*)p, b = *(const bf16x8*)(p + half);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] += (float)v[i];
+        for (int i = 0; i < 8; ++i) { lo[i] += (float)a[i]; hi[i] += (float)b[i]; }
     }
-    bf16x8 o;
+    if (cs) {
+        const int pos = rope_pos ? rope_pos[m] : (int)(m % S);
+        const float* c = cs + ((long)pos * half + e) * 2;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = (__bf16)acc[i];
-    *(bf16x8*)(out + m * ld_out + col) = o;
+        for (int i = 0; i < 8; ++i) {
+            const float a = bf2f(f2bf(lo[i])), b = bf2f(f2bf(hi[i]));
+            lo[i] = a * c[2 * i] + b * c[2 * i + 1];
+            hi[i] = b * c[2 * i] - a * c[2 * i + 1];
+        }
+    }
+    bf16x8 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { o0[i] = (__bf16)lo[i]; o1[i] = (__bf16)hi[i]; }
+    *(bf16x8*)(out + m * ld_out + (long)hk * hd + e) = o0;
+    *(bf16x8*)(out + m * ld_out + (long)hk * hd + e + half) = o1;
 }
 
 template <typename K>
@@ -571,18 +1136,35 @@ extern "C" int rv_attn_fwd_gqa(const void* q, int64_t ld_q, const void* k, int64
     return rv_check_launch();
 }
 
+extern "C" int rv_attn_fwd_nat(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v, void* out, int64_t ld_o,
+                               float* lse, const int32_t* lens, const int32_t* cu_rows, int B, int H, int H_kv, int S, int S_pad, int HD,
+                               int causal, float scale, const void* zeros16, void* stream) {
+    if (!q || !k || !v || !out || !zeros16 || B <= 0 || H <= 0 || S <= 0 || H_kv <= 0 || H % H_kv) return RV_ERR_ARG;
+    if (HD != 128 || (S_pad & 63) || S_pad < S) return RV_ERR_ARG;
+    if ((ld_q & 7) || (ld_k & 7) || (ld_v & 7) || (ld_o & 3) || !aligned_ok(q) || !aligned_ok(k) || !aligned_ok(v)) return RV_ERR_ARG;
+    AttnParams P = {};
+    P.q = (const bf16*)q; P.k = (const bf16*)k; P.v = (const bf16*)v; P.out = (bf16*)out; P.lse = lse; P.lens = lens; P.cu = cu_rows;
+    P.zeros = (const bf16*)zeros16; P.ld_q = ld_q; P.ld_k = ld_k; P.ld_v = ld_v; P.ld_o = ld_o;
+    P.B = B; P.H = H; P.S = S; P.S_pad = S_pad; P.scale = scale; P.Hkv = H_kv; P.nrep = H / H_kv;
+    dim3 grid((S + 127) / 128, H, B);
+    const int smem = 2 * 2 * 64 * 256;
+    if (causal) { set_smem(attn_fwd_nat_kernel<true>, smem); hipLaunchKernelGGL(attn_fwd_nat_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, P); }
+    else { set_smem(attn_fwd_nat_kernel<false>, smem); hipLaunchKernelGGL(attn_fwd_nat_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, P); }
+    return rv_check_launch();
+}
+
 extern "C" int rv_attn_fwd(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* vT, void* out,
                            int64_t ld_o, float* lse, const int32_t* lens, int B, int H, int S, int S_pad, int HD,
                            int causal, float scale, const void* zeros16, void* stream) {
     return rv_attn_fwd_gqa(q, ld_q, k, ld_k, vT, out, ld_o, lse, lens, nullptr, B, H, H, S, S_pad, HD, causal, scale, zeros16, stream);
 }
 
-extern "C" int rv_attn_bwd_gqa(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v,
+extern "C" int rv_attn_bwd_gqa_rope(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v,
                                const void* o, int64_t ld_o, const void* dout, int64_t ld_do, const void* qT, const void* kT,
                                const void* doT, const float* lse, float* delta, void* dq, int64_t ld_dq, void* dk,
                                int64_t ld_dk, void* dv, int64_t ld_dv, const int32_t* lens, const int32_t* cu_rows, int total_rows,
                                int B, int H, int H_kv, int S, int S_pad, int HD, int causal, float scale, void* workspace, int64_t workspace_bytes,
-                               const void* zeros16, void* stream) {
+                               const float* rope_cos_sin, const int32_t* rope_positions, const void* zeros16, void* stream) {
     if (!q || !k || !v || !o || !dout || !qT || !kT || !doT || !lse || !delta || !dq || !dk || !dv || !zeros16) return RV_ERR_ARG;
     if (H_kv <= 0 || H <= 0 || H % H_kv) return RV_ERR_ARG;
     if ((HD != 64 && HD != 128) || (S_pad & 63) || S_pad < S || B <= 0 || H <= 0 || S <= 0) return RV_ERR_ARG;
@@ -595,6 +1177,8 @@ extern "C" int rv_attn_bwd_gqa(const void* q, int64_t ld_q, const void* k, int64
     P.zeros = (const bf16*)zeros16;
     P.ld_q = ld_q; P.ld_k = ld_k; P.ld_v = ld_v; P.ld_o = ld_o; P.ld_do = ld_do; P.ld_dq = ld_dq; P.ld_dk = ld_dk; P.ld_dv = ld_dv;
     P.B = B; P.H = H; P.S = S; P.S_pad = S_pad; P.scale = scale; P.Hkv = H_kv; P.nrep = H / H_kv;
+    if (rope_cos_sin && ((((uintptr_t)rope_cos_sin) & 15) || (cu_rows && !rope_positions))) return RV_ERR_ARG;
+    P.rope_cs = rope_cos_sin; P.rope_pos = rope_positions; P.rope_dk = 1;
     hipStream_t st = (hipStream_t)stream;
     // 8 waves per block (2 per SIMD): dQ pass = 256 query rows per block, dK/dV pass = 128 keys per block (16 per wave)
     // and one block per KEY/VALUE head (it walks the head's H / H_kv query heads)
@@ -608,7 +1192,7 @@ extern "C" int rv_attn_bwd_gqa(const void* q, int64_t ld_q, const void* k, int64
     const bool expand = P.nrep > 1 && workspace && workspace_bytes >= need && (((uintptr_t)workspace) & 15) == 0 &&
                         (long)grid_dkv.x * H_kv * B < 2048;
     if (expand) {
-        PK.kdiv = P.nrep; PK.qrep = 1;
+        PK.kdiv = P.nrep; PK.qrep = 1; PK.rope_dk = 0;       // partial dK rows are summed first, then un-rotated once
         PK.dk = (bf16*)workspace; PK.dv = (bf16*)workspace + (int64_t)rows_all * H * HD;
         PK.ld_dk = PK.ld_dv = (long)H * HD;
         grid_dkv.y = H;
@@ -626,11 +1210,77 @@ extern "C" int rv_attn_bwd_gqa(const void* q, int64_t ld_q, const void* k, int64
     else { if (causal) LAUNCH_BWD(64, true); else LAUNCH_BWD(64, false); }
 #undef LAUNCH_BWD
     if (expand) {
-        const long rows = rows_all, total = rows * (H_kv * HD / 8);
-        hipLaunchKernelGGL(group_sum_heads_kernel, dim3((total + 255) / 256), dim3(256), 0, st, PK.dk, PK.ld_dk, P.dk, P.ld_dk, rows, H_kv, P.nrep, HD);
-        hipLaunchKernelGGL(group_sum_heads_kernel, dim3((total + 255) / 256), dim3(256), 0, st, PK.dv, PK.ld_dv, P.dv, P.ld_dv, rows, H_kv, P.nrep, HD);
+        const long rows = rows_all, total = rows * (H_kv * HD / 16);
+        hipLaunchKernelGGL(group_sum_heads_kernel, dim3((total + 255) / 256), dim3(256), 0, st, PK.dk, PK.ld_dk, P.dk, P.ld_dk, rows, H_kv, P.nrep, HD,
+                           rope_cos_sin, rope_positions, cu_rows, S);
+        hipLaunchKernelGGL(group_sum_heads_kernel, dim3((total + 255) / 256), dim3(256), 0, st, PK.dv, PK.ld_dv, P.dv, P.ld_dv, rows, H_kv, P.nrep, HD,
+                           (const float*)nullptr, (const int32_t*)nullptr, cu_rows, S);
     }
     return rv_check_launch();
+}
+
+
+extern "C" int rv_attn_bwd_nat(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v, const void* o, int64_t ld_o,
+                               const void* dout, int64_t ld_do, const float* lse, float* delta, void* dq, int64_t ld_dq, void* dk, int64_t ld_dk,
+                               void* dv, int64_t ld_dv, const int32_t* lens, const int32_t* cu_rows, int total_rows, int B, int H, int H_kv, int S,
+                               int S_pad, int HD, int causal, float scale, void* workspace, int64_t workspace_bytes, const float* rope_cos_sin,
+                               const int32_t* rope_positions, const void* zeros16, void* stream) {
+    if (!q || !k || !v || !o || !dout || !lse || !delta || !dq || !dk || !dv || !zeros16) return RV_ERR_ARG;
+    if (H_kv <= 0 || H <= 0 || H % H_kv || HD != 128 || (S_pad & 63) || S_pad < S || B <= 0 || S <= 0) return RV_ERR_ARG;
+    if ((ld_q & 7) || (ld_k & 7) || (ld_v & 7) || (ld_do & 7) || (ld_o & 7) || (ld_dq & 3) || (ld_dk & 3) || (ld_dv & 3)) return RV_ERR_ARG;
+    if (!aligned_ok(q) || !aligned_ok(k) || !aligned_ok(v) || !aligned_ok(dout) || !aligned_ok(o)) return RV_ERR_ARG;
+    if (rope_cos_sin && ((((uintptr_t)rope_cos_sin) & 15) || (cu_rows && !rope_positions))) return RV_ERR_ARG;
+    AttnParams P = {};
+    P.q = (const bf16*)q; P.k = (const bf16*)k; P.v = (const bf16*)v; P.o = (const bf16*)o; P.dout = (const bf16*)dout;
+    P.dq = (bf16*)dq; P.dk = (bf16*)dk; P.dv = (bf16*)dv; P.lse = (float*)lse; P.delta = delta; P.lens = lens; P.cu = cu_rows;
+    P.zeros = (const bf16*)zeros16;
+    P.ld_q = ld_q; P.ld_k = ld_k; P.ld_v = ld_v; P.ld_o = ld_o; P.ld_do = ld_do; P.ld_dq = ld_dq; P.ld_dk = ld_dk; P.ld_dv = ld_dv;
+    P.B = B; P.H = H; P.S = S; P.S_pad = S_pad; P.scale = scale; P.Hkv = H_kv; P.nrep = H / H_kv;
+    P.rope_cs = rope_cos_sin; P.rope_pos = rope_positions; P.rope_dk = 1;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid_dq((S + 255) / 256, H, B), grid_dkv((S + 127) / 128, H_kv, B);
+    AttnParams PK = P;
+    PK.kdiv = 1; PK.qrep = P.nrep;
+    const long rows_all = cu_rows ? (long)total_rows : (long)B * S;
+    if (cu_rows && total_rows <= 0) return RV_ERR_ARG;
+    const int64_t need = 2 * (int64_t)rows_all * H * HD * 2;
+    const bool expand = P.nrep > 1 && workspace && workspace_bytes >= need && (((uintptr_t)workspace) & 15) == 0 &&
+                        (long)grid_dkv.x * H_kv * B < 2048;
+    if (expand) {     // few key/value heads and a long causal sequence: per-query-head blocks + a group sum balance better
+        PK.kdiv = P.nrep; PK.qrep = 1; PK.rope_dk = 0;
+        PK.dk = (bf16*)workspace; PK.dv = (bf16*)workspace + (int64_t)rows_all * H * HD;
+        PK.ld_dk = PK.ld_dv = (long)H * HD;
+        grid_dkv.y = H;
+    }
+    const int smem_dq = 2 * 2 * 64 * 256, smem_dkv = 2 * (2 * 64 * 256 + 1024);
+#define LAUNCH_BWD_NAT(C_)                                                                                 \
+    do {                                                                                                   \
+        set_smem(attn_bwd_dq_nat_kernel<C_, 8>, smem_dq);                                                  \
+        set_smem(attn_bwd_dkv_nat_kernel<C_, 8>, smem_dkv);                                                \
+        hipLaunchKernelGGL((attn_bwd_dq_nat_kernel<C_, 8>), grid_dq, dim3(512), smem_dq, st, P);           \
+        hipLaunchKernelGGL((attn_bwd_dkv_nat_kernel<C_, 8>), grid_dkv, dim3(512), smem_dkv, st, PK);       \
+    } while (0)
+    if (causal) LAUNCH_BWD_NAT(true); else LAUNCH_BWD_NAT(false);
+#undef LAUNCH_BWD_NAT
+    if (expand) {
+        const long total = rows_all * (H_kv * HD / 16);
+        hipLaunchKernelGGL(group_sum_heads_kernel, dim3((total + 255) / 256), dim3(256), 0, st, PK.dk, PK.ld_dk, P.dk, P.ld_dk, rows_all, H_kv, P.nrep, HD,
+                           rope_cos_sin, rope_positions, cu_rows, S);
+        hipLaunchKernelGGL(group_sum_heads_kernel, dim3((total + 255) / 256), dim3(256), 0, st, PK.dv, PK.ld_dv, P.dv, P.ld_dv, rows_all, H_kv, P.nrep, HD,
+                           (const float*)nullptr, (const int32_t*)nullptr, cu_rows, S);
+    }
+    return rv_check_launch();
+}
+
+extern "C" int rv_attn_bwd_gqa(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v,
+                               const void* o, int64_t ld_o, const void* dout, int64_t ld_do, const void* qT, const void* kT,
+                               const void* doT, const float* lse, float* delta, void* dq, int64_t ld_dq, void* dk,
+                               int64_t ld_dk, void* dv, int64_t ld_dv, const int32_t* lens, const int32_t* cu_rows, int total_rows,
+                               int B, int H, int H_kv, int S, int S_pad, int HD, int causal, float scale, void* workspace, int64_t workspace_bytes,
+                               const void* zeros16, void* stream) {
+    return rv_attn_bwd_gqa_rope(q, ld_q, k, ld_k, v, ld_v, o, ld_o, dout, ld_do, qT, kT, doT, lse, delta, dq, ld_dq, dk, ld_dk, dv, ld_dv,
+                                lens, cu_rows, total_rows, B, H, H_kv, S, S_pad, HD, causal, scale, workspace, workspace_bytes, nullptr, nullptr,
+                                zeros16, stream);
 }
 
 extern "C" int rv_attn_bwd(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v,

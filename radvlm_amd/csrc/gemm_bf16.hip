@@ -34,7 +34,14 @@ struct GemmParams {
     // MODE 3 (tail split): blocks [0, n_full) compute whole tiles; the remaining tiles of the last, partly filled round are
     // each split over `splits` K-slices (fp32 partial tiles in ws, combined by tail_reduce_kernel)
     int n_full;
+    // fused epilogues of the 256x256 kernel (EPI template parameter):
+    //   EPI_ROPE        C = rope(A B^T + bias) on columns < rope_cols (q heads then k heads), table cs[pos][hd/2][cos,sin]
+    //   EPI_SWIGLU_FWD  B = [gate; up] rows ([2F, K]); C = gate|up [M, 2F], C2 = silu(gate) * up [M, F]
+    //   EPI_SWIGLU_BWD  acc = d(act) [M, F]; G = gate|up [M, 2F]; C = d(gate|up) [M, 2F]
+    const float* rope_cs; const int* rope_pos; int rope_S, rope_cols, rope_hd;
+    int F; bf16* C2; long ldc2; const bf16* G; long ldg;
 };
+enum { EPI_NONE = 0, EPI_ROPE = 1, EPI_SWIGLU_FWD = 2, EPI_SWIGLU_BWD = 3 };
 
 // Epilogue activations, kept to a few straight-line instructions each: the epilogue is unrolled 16 x 8 times and inlining libm's
 // erff / tanhf there pushed it past LLVM's pragma-unroll threshold -- the loops over the accumulator tile were then left
@@ -205,9 +212,15 @@ DEVINL int tswz(int m) { return ((m & 3) | (((m >> 3) & 1) << 2)) << 1; }
 // same interleave is a different column start of the tr read, no staging change.
 DEVINL int perm32f(int r) { return (r & ~31) + (((r & 15) >> 2) << 3) + (((r >> 4) & 1) << 2) + (r & 3); }
 
-template <bool T, bool PERM = false>
+// BMAP (B operand of the fused-epilogue kernels): which weight row a tile column holds, chosen so that the two values an epilogue
+// combines sit in the SAME lane (accumulator groups a = 0 and a = 1 of a lane hold tile columns 64 wc + 8 q + j and + 32):
+//   BMAP 1 (RoPE, head_dim 128): a tile = two heads; within a head, column 64 wcl + 32 a + 8 q + j holds head dimension
+//           64 a + 32 wcl + 8 q + j, i.e. bits 5 and 6 swapped -> a lane's two groups are the rotation partners e and e + 64;
+//   BMAP 2 (SwiGLU): a tile = 128 features; column 64 wc + 32 a + 8 q + j holds row a * F + 128 tn + 32 wc + 8 q + j of the
+//           stacked [gate; up] weight -> group 0 is gate(f), group 1 is up(f) for the same 8 features.
+template <bool T, bool PERM = false, int BMAP = 0>
 DEVINL void stage_half(const bf16* __restrict__ src, long ld, int feat0, int nfeat, int k0, int K, const bf16* zeros,
-                       char* lds, int wid, int lane) {
+                       char* lds, int wid, int lane, int h = 0, int F = 0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int it = i * 8 + wid;           // wave-instruction index 0..15
@@ -216,8 +229,20 @@ DEVINL void stage_half(const bf16* __restrict__ src, long ld, int feat0, int nfe
         if (!T) {
             const int r = c >> 3, p = c & 7;
             const int lc = p ^ ((r >> 1) & 7);
-            const int gr = feat0 + (PERM ? perm32f(r) : r), gk = k0 + lc * 8;
-            g = (gr < nfeat && gk < K) ? (src + (long)gr * ld + gk) : zeros;
+            int gr = feat0 + (PERM ? perm32f(r) : r);
+            const int gk = k0 + lc * 8;
+            bool ok = gr < nfeat;
+            if (BMAP == 1) {          // feat0 = first row of this half (one head of 128)
+                const int f = perm32f(r);
+                gr = feat0 + ((f & 31) | ((f & 32) << 1) | ((f & 64) >> 1));
+                ok = gr < nfeat;
+            } else if (BMAP == 2) {   // feat0 = 128 * tn (first feature of the tile); h = which half of the tile's 256 columns
+                const int cc = h * 128 + perm32f(r);
+                const int f = feat0 + 32 * (cc >> 6) + (cc & 31);
+                gr = ((cc >> 5) & 1) * F + f;
+                ok = f < F;
+            }
+            g = (ok && gk < K) ? (src + (long)gr * ld + gk) : zeros;
         } else {
             const int r = c >> 4, p = c & 15;
             const int lc = p ^ tswz(r);
@@ -458,6 +483,22 @@ DEVINL void epilogue_256(const f32x4 (&acc)[8][4], const GemmParams& P, int m0, 
     // n = n0 + wc*64 + 32a + 8*(lane>>4) + {0..7}: acc[i][2a][0..3] then acc[i][2a+1][0..3]
     const bool n_vec_ok = (P.N % 8 == 0) && (P.ldc % 8 == 0) && (!P.R || P.ldr % 8 == 0) &&
                           ((((uintptr_t)P.C) | ((uintptr_t)P.R) | ((uintptr_t)P.bias)) & 15) == 0;
+#ifndef RV_NO_COMPACT_EPILOGUE
+    // the common case (plain bf16 product: every dgrad / wgrad-free forward GEMM of the decoder) gets a compact instruction stream:
+    // the general path below is ~20k instructions of mostly untaken branches per kernel, fetched once per tile
+    if (MODE == 0 && !P.bias && P.act == RV_ACT_NONE && !P.R && !P.out_f32 && P.alpha == 1.f && n_vec_ok) {
+        static_for<16>([&](auto ia) {
+            constexpr int i = decltype(ia)::value >> 1, a = decltype(ia)::value & 1;
+            const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+            const int n = n0 + wc * 64 + 32 * a + 8 * (lane >> 4);
+            if (m >= P.M || n >= P.N) return;
+            const f32x4 lo = acc[i][2 * a], hi = acc[i][2 * a + 1];
+            *(bf16x8*)((bf16*)P.C + (long)m * P.ldc + n) =
+                bf16x8{f2bf(lo[0]), f2bf(lo[1]), f2bf(lo[2]), f2bf(lo[3]), f2bf(hi[0]), f2bf(hi[1]), f2bf(hi[2]), f2bf(hi[3])};
+        });
+        return;
+    }
+#endif
     static_for<16>([&](auto ia) {
         constexpr int i = decltype(ia)::value >> 1, a = decltype(ia)::value & 1;
         const int m = m0 + wr * 128 + i * 16 + (lane & 15);
@@ -529,6 +570,97 @@ DEVINL void epilogue_256(const f32x4 (&acc)[8][4], const GemmParams& P, int m0, 
     });
 }
 
+DEVINL float rbf16(float x) { return bf2f(f2bf(x)); }
+DEVINL void store8(bf16* p, const float (&v)[8]) {
+    *(bf16x8*)p = bf16x8{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3]), f2bf(v[4]), f2bf(v[5]), f2bf(v[6]), f2bf(v[7])};
+}
+
+// Fused epilogues: a lane holds, for row m = m0 + wr*128 + i*16 + (lane&15), tile columns 64 wc + 8 q + {0..7} (group a = 0:
+// acc[i][0], acc[i][1]) and the same + 32 (group a = 1: acc[i][2], acc[i][3]), q = lane >> 4.  The B-row maps above make the pair
+// of groups exactly what the epilogue combines, so everything is lane-local; all stores are 16-byte vectors.
+template <int EPI>
+DEVINL void epilogue_fused(const f32x4 (&acc)[8][4], const GemmParams& P, int m0, int tn, int wr, int wc, int lane) {
+    const int q = lane >> 4;
+    static_for<8>([&](auto ii) {
+        constexpr int i = decltype(ii)::value;
+        const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+        if (m >= P.M) return;
+        float lo[8] = {acc[i][0][0], acc[i][0][1], acc[i][0][2], acc[i][0][3], acc[i][1][0], acc[i][1][1], acc[i][1][2], acc[i][1][3]};
+        float hi[8] = {acc[i][2][0], acc[i][2][1], acc[i][2][2], acc[i][2][3], acc[i][3][0], acc[i][3][1], acc[i][3][2], acc[i][3][3]};
+        if (EPI == EPI_ROPE) {
+            // q/k projection + rotary embedding (modeling_llama.py:332-338 then :167-198): column e of a head pairs with e + hd/2
+            const int half = P.rope_hd >> 1;
+            int nlo, e0;
+            if (P.rope_hd == 128) { e0 = 32 * (wc & 1) + 8 * q; nlo = tn * BN2 + (wc >> 1) * 128 + e0; }
+            else { e0 = 8 * q; nlo = tn * BN2 + wc * 64 + e0; }              // head_dim 64: partners 32 apart, natural order
+            const int nhi = nlo + half;
+            if (nlo >= P.N) return;
+            if (P.bias) {
+                const bf16x8 b0 = *(const bf16x8*)(P.bias + nlo), b1 = *(const bf16x8*)(P.bias + nhi);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { lo[r] += bf2f(b0[r]); hi[r] += bf2f(b1[r]); }
+            }
+            if (nlo < P.rope_cols) {
+                const int pos = P.rope_pos ? P.rope_pos[m] : (m % P.rope_S);
+                const float* cs = P.rope_cs + ((long)pos * half + e0) * 2;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const f32x4 t = *(const f32x4*)(cs + 4 * r4);            // cos, sin of two consecutive dimensions
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int r = 2 * r4 + u;
+                        const float co = t[2 * u], si = t[2 * u + 1];
+                        // the unfused path stored the projection in bf16 before rotating it: keep that rounding point
+                        const float a = rbf16(lo[r]), b = rbf16(hi[r]);
+                        lo[r] = a * co - b * si;
+                        hi[r] = b * co + a * si;
+                    }
+                }
+            }
+            bf16* cp = (bf16*)P.C + (long)m * P.ldc;
+            store8(cp + nlo, lo);
+            store8(cp + nhi, hi);
+        } else if (EPI == EPI_SWIGLU_FWD) {
+            // LlamaMLP (modeling_llama.py:226): lo = gate(f .. f+7), hi = up(f .. f+7)
+            const int f = tn * 128 + 32 * wc + 8 * q;
+            if (f >= P.F) return;
+            float a[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float g = rbf16(lo[r]), u = rbf16(hi[r]);               // gate|up are stored in bf16; the activation reads them back
+                a[r] = rbf16(g / (1.f + __expf(-g))) * u;
+            }
+            bf16* gp = (bf16*)P.C + (long)m * P.ldc;
+            store8(gp + f, lo);
+            store8(gp + P.F + f, hi);
+            store8(P.C2 + (long)m * P.ldc2 + f, a);
+        }
+    });
+    if (EPI == EPI_SWIGLU_BWD) {
+        // acc = d(act) of columns n .. n+7 (natural column order); d gate = da * up * silu'(gate), d up = da * silu(gate)
+        static_for<16>([&](auto ia) {
+            constexpr int i = decltype(ia)::value >> 1, a = decltype(ia)::value & 1;
+            const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+            const int n = tn * BN2 + wc * 64 + 32 * a + 8 * q;
+            if (m >= P.M || n >= P.F) return;
+            const f32x4 x0 = acc[i][2 * a], x1 = acc[i][2 * a + 1];
+            const float da[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+            const bf16x8 gv = *(const bf16x8*)(P.G + (long)m * P.ldg + n), uv = *(const bf16x8*)(P.G + (long)m * P.ldg + P.F + n);
+            float dg[8], du[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float g = bf2f(gv[r]), u = bf2f(uv[r]), d = rbf16(da[r]);   // d(act) was a bf16 tensor in the unfused path
+                const float sg = 1.f / (1.f + __expf(-g));
+                du[r] = d * (g * sg);
+                dg[r] = d * u * (sg * (1.f + g * (1.f - sg)));
+            }
+            bf16* cp = (bf16*)P.C + (long)m * P.ldc;
+            store8(cp + n, dg);
+            store8(cp + P.F + n, du);
+        });
+    }
+}
+
 #ifdef RV_STAMPS
 // Diagnostic build only (tools/gemm_stamps.py): wall-clock stamps (s_memrealtime, 100 MHz) of wave 0 of every block at kernel
 // entry, first MFMA-ready barrier, end of the K loop and end of the epilogue (after its stores are acknowledged) -> a buffer
@@ -540,7 +672,7 @@ extern "C" int rv_debug_set_stamp_buffer(void* p) { g_stamp_host = (long long*)p
 #define RV_STAMP(i) do { } while (0)
 #endif
 
-template <bool TA, bool TB, int MODE>
+template <bool TA, bool TB, int MODE, int EPI = EPI_NONE>
 __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wid = wave_id(), lane = lane_id();
@@ -583,6 +715,10 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
     auto stageB = [&](int t, int h) {
         char* dst = smem + B_RING_OFF + ((t & 1) * 2 + h) * HALF_BYTES;
         if (MODE == 1 && t >= nt1) stage_half<TB, true>(P.B2, P.ldb2, n0 + h * 128, P.N, (t - nt1) * BK, P.K2, P.zeros, dst, wid, lane);
+        else if (EPI == EPI_ROPE) {
+            if (P.rope_hd == 128) stage_half<TB, true, 1>(P.B, P.ldb, n0 + h * 128, P.N, (t0 + t) * BK, P.K, P.zeros, dst, wid, lane);
+            else stage_half<TB, true>(P.B, P.ldb, n0 + h * 128, P.N, (t0 + t) * BK, P.K, P.zeros, dst, wid, lane);
+        } else if (EPI == EPI_SWIGLU_FWD) stage_half<TB, true, 2>(P.B, P.ldb, tn * 128, P.N, (t0 + t) * BK, P.K, P.zeros, dst, wid, lane, h, P.F);
         else stage_half<TB, true>(P.B, P.ldb, n0 + h * 128, P.N, (t0 + t) * BK, P.K, P.zeros, dst, wid, lane);
     };
 
@@ -634,7 +770,8 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
             }
         return;
     }
-    epilogue_256<MODE == 3 ? 0 : MODE>(acc, P, m0, n0, wr, wc, lane, kslice);
+    if (EPI != EPI_NONE) epilogue_fused<EPI>(acc, P, m0, tn, wr, wc, lane);
+    else epilogue_256<MODE == 3 ? 0 : MODE>(acc, P, m0, n0, wr, wc, lane, kslice);
 #ifdef RV_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -834,4 +971,87 @@ extern "C" int rv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_
                                const void* bias, const void* residual, int64_t ldr, int M, int N, int K, int act,
                                int out_f32, int res_f32, const void* zeros16, void* stream) {
     return rv_gemm_bf16(A, lda, B, ldb, C, ldc, bias, residual, ldr, M, N, K, 0, 0, 1.0f, act, out_f32, res_f32, zeros16, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused-epilogue entry points (256x256 kernel, plain tiles).  Each falls back to the unfused sequence (GEMM, then the elementwise
+// kernel of ops.hip) when the output has too few 256x256 tiles for that kernel to be the right choice, or when a shape constraint of
+// the fused form does not hold -- results are bit-identical either way (the fused epilogues keep the unfused rounding points).
+template <int EPI, bool TB>
+static int launch_fused(GemmParams& P, int tiles_m, int tiles_n, hipStream_t st) {
+    static bool attr = false;      // once per instantiation (see the launch-configuration note above)
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_kernel_256<false, TB, 0, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2); attr = true; }
+    P.tiles_m = tiles_m; P.tiles_n = tiles_n; P.n_full = 0; P.splits = 1; P.ws = nullptr;
+    P.A2 = nullptr; P.B2 = nullptr; P.K2 = 0; P.lda2 = P.ldb2 = 0;
+    hipLaunchKernelGGL((gemm_kernel_256<false, TB, 0, EPI>), dim3(tiles_m * tiles_n), dim3(512), LDS_BYTES2, st, P);
+    return rv_check_launch();
+}
+static bool big_enough_for_256(int M, int N) {
+    const int cus = cu_budget();
+    const long tiles256 = (long)((M + BM2 - 1) / BM2) * ((N + BN2 - 1) / BN2);
+    const long tiles128 = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int force = g_force_kernel;
+    if (force) return force == 2;
+    return 4.0 * (double)((tiles256 + cus - 1) / cus) <= 2.0 * 1.15 * (double)((tiles128 + 2 * cus - 1) / (2 * cus));
+}
+
+extern "C" int rv_gemm_rope_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
+                                 int M, int N, int K, const float* cos_sin, const int32_t* positions, int S, int rope_heads, int hd,
+                                 void* workspace, int64_t workspace_bytes, const void* zeros16, void* stream) {
+    if (!A || !B || !C || !cos_sin || !zeros16 || M <= 0 || N <= 0 || K <= 0 || rope_heads <= 0 || (long)rope_heads * hd > N) return RV_ERR_ARG;
+    if ((hd & 15) || (!positions && S <= 0)) return RV_ERR_ARG;
+    const bool fused = (hd == 128 || hd == 64) && (N % 8 == 0) && (ldc % 8 == 0) && (N % hd == 0) && big_enough_for_256(M, N) &&
+                       ((((uintptr_t)C) | ((uintptr_t)bias) | ((uintptr_t)cos_sin)) & 15) == 0 && !(lda & 7) && !(ldb & 7) && !(K & 7);
+    if (!fused) {
+        int rc = rv_gemm_bf16_ex(A, lda, B, ldb, C, ldc, bias, nullptr, 0, M, N, K, 0, 0, 1.f, RV_ACT_NONE, 0, 0, nullptr, 0, nullptr, 0, 0,
+                                 workspace, workspace_bytes, zeros16, stream);
+        if (rc != RV_OK) return rc;
+        return positions ? rv_rope_inplace_pos(C, ldc, cos_sin, positions, M, rope_heads, hd, 1, 1, stream)
+                         : rv_rope_inplace(C, ldc, cos_sin, M, S, rope_heads, hd, 1, 1, stream);
+    }
+    if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)zeros16) & 15) return RV_ERR_ARG;
+    GemmParams P = {};
+    P.A = (const bf16*)A; P.B = (const bf16*)B; P.C = C; P.bias = (const bf16*)bias; P.zeros = (const bf16*)zeros16;
+    P.lda = lda; P.ldb = ldb; P.ldc = ldc; P.M = M; P.N = N; P.K = K; P.alpha = 1.f;
+    P.rope_cs = cos_sin; P.rope_pos = positions; P.rope_S = S > 0 ? S : 1; P.rope_cols = rope_heads * hd; P.rope_hd = hd;
+    return launch_fused<EPI_ROPE, false>(P, (M + BM2 - 1) / BM2, (N + BN2 - 1) / BN2, (hipStream_t)stream);
+}
+
+extern "C" int rv_gemm_swiglu_fwd_bf16(const void* A, int64_t lda, const void* Wgu, int64_t ldb, void* GU, int64_t ldgu, void* ACT,
+                                       int64_t ldact, int M, int F, int K, void* workspace, int64_t workspace_bytes, const void* zeros16,
+                                       void* stream) {
+    if (!A || !Wgu || !GU || !ACT || !zeros16 || M <= 0 || F <= 0 || K <= 0 || (F & 7) || (ldgu & 7) || (ldact & 7)) return RV_ERR_ARG;
+    const bool fused = big_enough_for_256(M, 2 * F) && ((((uintptr_t)GU) | ((uintptr_t)ACT)) & 15) == 0 && !(lda & 7) && !(ldb & 7) && !(K & 7);
+    if (!fused) {
+        int rc = rv_gemm_bf16_ex(A, lda, Wgu, ldb, GU, ldgu, nullptr, nullptr, 0, M, 2 * F, K, 0, 0, 1.f, RV_ACT_NONE, 0, 0, nullptr, 0, nullptr,
+                                 0, 0, workspace, workspace_bytes, zeros16, stream);
+        if (rc != RV_OK) return rc;
+        return rv_swiglu_fwd(GU, ldgu, ACT, ldact, M, F, stream);
+    }
+    if (((uintptr_t)A | (uintptr_t)Wgu | (uintptr_t)zeros16) & 15) return RV_ERR_ARG;
+    GemmParams P = {};
+    P.A = (const bf16*)A; P.B = (const bf16*)Wgu; P.C = GU; P.zeros = (const bf16*)zeros16;
+    P.lda = lda; P.ldb = ldb; P.ldc = ldgu; P.M = M; P.N = 2 * F; P.K = K; P.alpha = 1.f;
+    P.F = F; P.C2 = (bf16*)ACT; P.ldc2 = ldact;
+    return launch_fused<EPI_SWIGLU_FWD, false>(P, (M + BM2 - 1) / BM2, (F + 127) / 128, (hipStream_t)stream);
+}
+
+extern "C" int rv_gemm_swiglu_bwd_bf16(const void* dY, int64_t ldy, const void* Wd, int64_t ldw, const void* GU, int64_t ldgu, void* dGU,
+                                       int64_t lddgu, void* dact_scratch, int64_t ld_dact, int M, int F, int K, void* workspace,
+                                       int64_t workspace_bytes, const void* zeros16, void* stream) {
+    if (!dY || !Wd || !GU || !dGU || !zeros16 || M <= 0 || F <= 0 || K <= 0 || (F & 7) || (ldgu & 7) || (lddgu & 7)) return RV_ERR_ARG;
+    const bool fused = big_enough_for_256(M, F) && ((((uintptr_t)GU) | ((uintptr_t)dGU)) & 15) == 0 && !(ldy & 7) && !(ldw & 7) && !(K & 7);
+    if (!fused) {
+        if (!dact_scratch || (ld_dact & 7)) return RV_ERR_ARG;      // the unfused sequence needs d(act) [M, F] as a real tensor
+        int rc = rv_gemm_bf16_ex(dY, ldy, Wd, ldw, dact_scratch, ld_dact, nullptr, nullptr, 0, M, F, K, 0, 1, 1.f, RV_ACT_NONE, 0, 0, nullptr, 0,
+                                 nullptr, 0, 0, workspace, workspace_bytes, zeros16, stream);
+        if (rc != RV_OK) return rc;
+        return rv_swiglu_bwd(dact_scratch, ld_dact, GU, ldgu, dGU, lddgu, M, F, stream);
+    }
+    if (((uintptr_t)dY | (uintptr_t)Wd | (uintptr_t)zeros16) & 15) return RV_ERR_ARG;
+    GemmParams P = {};
+    P.A = (const bf16*)dY; P.B = (const bf16*)Wd; P.C = dGU; P.zeros = (const bf16*)zeros16;
+    P.lda = ldy; P.ldb = ldw; P.ldc = lddgu; P.M = M; P.N = F; P.K = K; P.alpha = 1.f;
+    P.F = F; P.G = (const bf16*)GU; P.ldg = ldgu;
+    return launch_fused<EPI_SWIGLU_BWD, true>(P, (M + BM2 - 1) / BM2, (F + BN2 - 1) / BN2, (hipStream_t)stream);
 }

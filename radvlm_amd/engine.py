@@ -132,6 +132,9 @@ class LlavaEngine:
         self.ctx = None
         self.grad_accum_started = False
         self.loss_scale = 1.0
+        import os
+        # A/B switch (measurement only): RV_FUSED=0 runs the unfused sequences (GEMM, then rope / swiglu kernels); results are bit-identical
+        self.fused = os.environ.get("RV_FUSED", "1") != "0"
         assert padding_side in ("right", "left")
         self.padding_side = padding_side     # config.tokenizer_padding_side (llava_arch.py:520-524)
 
@@ -297,8 +300,11 @@ class LlavaEngine:
             h, st1 = r if keep else (r, None)
             wqkv, bqkv, wo = self._vis_attn_weights(i)
             qkv = ops.gemm_nt(h, wqkv, bias=bqkv)
-            vT = ops.transpose_heads(qkv[:, 2 * dvp:], n, N, H, hp, n_pad)
-            a, lse = ops.attn_fwd(qkv[:, :dvp], qkv[:, dvp:2 * dvp], vT, n, N, H, hp, n_pad, causal=False, scale=hd ** -0.5)
+            if hp == 128:     # natural-layout kernel: no V^T copy
+                a, lse = ops.attn_fwd(qkv[:, :dvp], qkv[:, dvp:2 * dvp], None, n, N, H, hp, n_pad, causal=False, scale=hd ** -0.5, v=qkv[:, 2 * dvp:])
+            else:
+                vT = ops.transpose_heads(qkv[:, 2 * dvp:], n, N, H, hp, n_pad)
+                a, lse = ops.attn_fwd(qkv[:, :dvp], qkv[:, dvp:2 * dvp], vT, n, N, H, hp, n_pad, causal=False, scale=hd ** -0.5)
             x1 = ops.gemm_nt(a, wo, bias=f.view(p + "self_attn.out_proj.bias"), residual=x)
             r = ln(x1, p + "layer_norm2.weight", p + "layer_norm2.bias")
             h2, st2 = r if keep else (r, None)
@@ -531,11 +537,18 @@ class LlavaEngine:
             sv = {}
             if self.lora:
                 qkv = self._lora_linear(h1, lv["qkv"], i, self._MODS_QKV(d), sv, bias=lv.get("bqkv"))   # frozen q/k/v biases (Qwen2)
-            else:
+                ops.rope_inplace(qkv, cs, S, H + Hkv, hd, 1, 1, positions=pos)   # q heads then k heads: one run of H + Hkv heads
+            elif not self.fused:
                 qkv = ops.gemm_nt(h1, lv["qkv"], bias=lv.get("bqkv"))
-            ops.rope_inplace(qkv, cs, S, H + Hkv, hd, 1, 1, positions=pos)   # q heads then k heads: one run of H + Hkv heads
-            vT = ops.transpose_heads(qkv[:, d + kvd:], B, S, Hkv, hd, s_pad, cu=cu)
-            attn, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d:d + kvd], vT, B, S, H, hd, s_pad, causal=True, lens=lens, kv_heads=Hkv, cu=cu)
+                ops.rope_inplace(qkv, cs, S, H + Hkv, hd, 1, 1, positions=pos)
+            else:       # q|k|v projection with the rotary embedding in the GEMM epilogue
+                qkv = ops.gemm_rope(h1, lv["qkv"], cs, S, H + Hkv, hd, bias=lv.get("bqkv"), positions=pos)
+            if hd == 128:     # natural-layout kernel: K and V tiles are staged as they lie in memory (no V^T copy)
+                attn, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d:d + kvd], None, B, S, H, hd, s_pad, causal=True, lens=lens, kv_heads=Hkv, cu=cu,
+                                         v=qkv[:, d + kvd:])
+            else:
+                vT = ops.transpose_heads(qkv[:, d + kvd:], B, S, Hkv, hd, s_pad, cu=cu)
+                attn, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d:d + kvd], vT, B, S, H, hd, s_pad, causal=True, lens=lens, kv_heads=Hkv, cu=cu)
             if self.lora:
                 x_mid = self._lora_linear(attn, lv["o"], i, (("self_attn.o_proj", 0, d),), sv, residual=x)
             else:
@@ -543,9 +556,12 @@ class LlavaEngine:
             h2, rstd2 = ops.rmsnorm_fwd(x_mid, lv["ln2"], self.eps)
             if self.lora:
                 gu = self._lora_linear(h2, lv["gu"], i, (("mlp.gate_proj", 0, F), ("mlp.up_proj", F, 2 * F)), sv)
-            else:
+                act = ops.swiglu_fwd(gu, F)
+            elif not self.fused:
                 gu = ops.gemm_nt(h2, lv["gu"])
-            act = ops.swiglu_fwd(gu, F)
+                act = ops.swiglu_fwd(gu, F)
+            else:       # gate|up projection and silu(gate) * up in one launch
+                gu, act = ops.gemm_swiglu_fwd(h2, lv["gu"], F)
             if self.lora:
                 x_out = self._lora_linear(act, lv["down"], i, (("mlp.down_proj", 0, d),), sv, residual=x_mid)
             else:
@@ -686,16 +702,23 @@ class LlavaEngine:
             a = c["layers"][i]
             lv, gv = self._layer_views(i), self._layer_views(i, self.grads)
             sv = a["lora"]
-            dact = self._lm_linear_bwd(dx, a["act"], lv["down"], gv.get("down"), i, (("mlp.down_proj", 0, d),), sv)
-            dgu = ops.swiglu_bwd(dact, a["gu"], F)
+            if self.lora or not self.fused:
+                dact = self._lm_linear_bwd(dx, a["act"], lv["down"], gv.get("down"), i, (("mlp.down_proj", 0, d),), sv)
+                dgu = ops.swiglu_bwd(dact, a["gu"], F)
+            else:       # down_proj: weight gradient, then the input gradient with the SwiGLU backward in its epilogue (d(act) never stored)
+                self._linear_bwd(dx, a["act"], lv["down"], gv.get("down"), need_dx=False)
+                dgu = ops.gemm_swiglu_bwd(dx, lv["down"], a["gu"], F)
             dh2 = self._lm_linear_bwd(dgu, a["h2"], lv["gu"], gv.get("gu"), i, (("mlp.gate_proj", 0, F), ("mlp.up_proj", F, 2 * F)), sv)
             ops.rmsnorm_bwd(dh2, a["x_mid"], lv["ln2"], a["rstd2"], dx=dx, dx_add=True, dw=gv.get("ln2"), dw_accumulate=acc)
             dattn = self._lm_linear_bwd(dx, a["attn"], lv["o"], gv.get("o"), i, (("self_attn.o_proj", 0, d),), sv)
             qkv = a["qkv"]
             dqkv = torch.empty_like(qkv)
+            # the rotary embedding's adjoint runs in the dQ / dK epilogues: dqkv = gradient of the un-rotated q|k|v projection
             ops.attn_bwd(qkv[:, :d], qkv[:, d:d + kvd], qkv[:, d + kvd:], a["attn"], dattn, a["lse"], B, S, H, hd, s_pad, True,
-                         lens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:d + kvd], dv=dqkv[:, d + kvd:], kv_heads=Hkv, cu=cu)
-            ops.rope_inplace(dqkv, cs, S, H + Hkv, hd, 1, -1, positions=pos)
+                         lens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:d + kvd], dv=dqkv[:, d + kvd:], kv_heads=Hkv, cu=cu,
+                         rope=(cs, pos) if self.fused else None)
+            if not self.fused:
+                ops.rope_inplace(dqkv, cs, S, H + Hkv, hd, 1, -1, positions=pos)
             if "bqkv" in gv:
                 ops.bias_grad(dqkv, out=gv["bqkv"], accumulate=acc)
             dh1 = self._lm_linear_bwd(dqkv, a["h1"], lv["qkv"], gv.get("qkv"), i, self._MODS_QKV(d), sv)

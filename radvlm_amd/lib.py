@@ -26,6 +26,12 @@ _SIGS = {
                      _f32, _i32, _i32, _i32, _c_void_p, _c_void_p],
     "rv_gemm_bf16_ex": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i64, _i32, _i32, _i32, _i32, _i32,
                         _f32, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p, _i64, _i32, _c_void_p, _i64, _c_void_p, _c_void_p],
+    "rv_gemm_rope_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i32, _i32, _i32, _c_void_p, _c_void_p, _i32, _i32, _i32,
+                          _c_void_p, _i64, _c_void_p, _c_void_p],
+    "rv_gemm_swiglu_fwd_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _i32, _i32, _c_void_p, _i64, _c_void_p,
+                                _c_void_p],
+    "rv_gemm_swiglu_bwd_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _i32, _i32, _c_void_p,
+                                _i64, _c_void_p, _c_void_p],
     "rv_dropout_bf16": [_c_void_p, _c_void_p, _i64, _f32, ctypes.c_uint64, _c_void_p],
     "rv_dropout_add_bf16": [_c_void_p, _c_void_p, _i64, _f32, ctypes.c_uint64, _c_void_p],
     "rv_transpose_bf16": [_c_void_p, _i64, _i64, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _c_void_p],
@@ -48,6 +54,14 @@ _SIGS = {
     "rv_attn_bwd_gqa": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p,
                         _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i32,
                         _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _c_void_p, _i64, _c_void_p, _c_void_p],
+    "rv_attn_fwd_nat": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i32,
+                        _i32, _i32, _i32, _i32, _f32, _c_void_p, _c_void_p],
+    "rv_attn_bwd_nat": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i64,
+                        _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _c_void_p, _i64,
+                        _c_void_p, _c_void_p, _c_void_p, _c_void_p],
+    "rv_attn_bwd_gqa_rope": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p,
+                             _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _c_void_p, _i32,
+                             _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _c_void_p],
     "rv_transpose_bf16_varlen": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32,
                                  _c_void_p],
     "rv_rope_inplace_pos": [_c_void_p, _i64, _c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i32, _c_void_p],

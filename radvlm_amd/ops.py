@@ -94,6 +94,56 @@ def gemm(a, b, ta=False, tb=False, out=None, bias=None, residual=None, act=ACT_N
     return out
 
 
+def gemm_rope(a, b, cos_sin, S, rope_heads, hd, bias=None, positions=None, out=None):
+    """out[M,N] = rope(a[M,K] @ b[N,K]^T + bias): rotary embedding applied to the first rope_heads heads (q then k) in the epilogue."""
+    _chk(a), _chk(b)
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and a.stride(1) == 1 and b.stride(1) == 1
+    if out is None:
+        out = torch.empty(M, N, dtype=BF16, device=a.device)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == BF16
+    ws = default_workspace(a.device)
+    lib.call("rv_gemm_rope_bf16", a, a.stride(0), b, b.stride(0), out, out.stride(0), bias, M, N, K, cos_sin, positions, S, rope_heads, hd,
+             ws, ws.numel() * ws.element_size(), lib.zeros16(a.device))
+    return out
+
+
+def gemm_swiglu_fwd(a, wgu, F, gu=None, act=None):
+    """(gu [M,2F], act [M,F]) = (a @ wgu^T, silu(gate) * up) in one launch; wgu = stacked [gate; up] rows [2F, K]."""
+    _chk(a), _chk(wgu)
+    M, K = a.shape
+    assert wgu.shape == (2 * F, K) and a.stride(1) == 1 and wgu.stride(1) == 1
+    gu = torch.empty(M, 2 * F, dtype=BF16, device=a.device) if gu is None else gu
+    act = torch.empty(M, F, dtype=BF16, device=a.device) if act is None else act
+    ws = default_workspace(a.device)
+    lib.call("rv_gemm_swiglu_fwd_bf16", a, a.stride(0), wgu, wgu.stride(0), gu, gu.stride(0), act, act.stride(0), M, F, K,
+             ws, ws.numel() * ws.element_size(), lib.zeros16(a.device))
+    return gu, act
+
+
+def gemm_swiglu_bwd(dy, wd, gu, F, dgu=None):
+    """dgu [M,2F] = swiglu'(gu) * (dy [M,d] @ wd [d,F]): down_proj's input gradient with the activation backward in the epilogue."""
+    _chk(dy), _chk(wd), _chk(gu)
+    M, K = dy.shape
+    assert wd.shape == (K, F) and gu.shape == (M, 2 * F) and dy.stride(1) == 1 and wd.stride(1) == 1 and gu.stride(1) == 1
+    dgu = torch.empty_like(gu) if dgu is None else dgu
+    ws = default_workspace(dy.device)
+    # d(act) as a tensor exists only in the unfused fallback (small shapes): allocate it there, not for the 7B step
+    small = M * F <= (1 << 24)
+    scratch = torch.empty(M, F, dtype=BF16, device=dy.device) if small else None
+    try:
+        lib.call("rv_gemm_swiglu_bwd_bf16", dy, dy.stride(0), wd, wd.stride(0), gu, gu.stride(0), dgu, dgu.stride(0), scratch,
+                 F if small else 0, M, F, K, ws, ws.numel() * ws.element_size(), lib.zeros16(dy.device))
+    except lib.RadvlmHipError:
+        if small:
+            raise
+        scratch = torch.empty(M, F, dtype=BF16, device=dy.device)     # a large shape that still took the fallback (forced kernel choice)
+        lib.call("rv_gemm_swiglu_bwd_bf16", dy, dy.stride(0), wd, wd.stride(0), gu, gu.stride(0), dgu, dgu.stride(0), scratch, F, M, F, K,
+                 ws, ws.numel() * ws.element_size(), lib.zeros16(dy.device))
+    return dgu
+
+
 def transpose(x, r_pad=None, out=None):
     """x [R,C] (unit inner stride) -> [C, r_pad] with zero padding."""
     _chk(x)
@@ -240,26 +290,44 @@ def rope_inplace(x, cos_sin, S, heads, hd, nsec, direction=1, positions=None):
     return x
 
 
-def attn_fwd(q, k, vT, B, S, H, hd, s_pad, causal, lens=None, scale=None, out=None, lse=None, kv_heads=None, cu=None):
-    """q, k: token-major [(B*S), H*hd] / [(B*S), kv_heads*hd] views; vT [B,kv_heads,hd,s_pad].
-    Returns (out [(B*S), H*hd], lse fp32 [B,H,s_pad])."""
+def attn_fwd(q, k, vT, B, S, H, hd, s_pad, causal, lens=None, scale=None, out=None, lse=None, kv_heads=None, cu=None, v=None):
+    """q, k: token-major [(B*S), H*hd] / [(B*S), kv_heads*hd] views; vT [B,kv_heads,hd,s_pad], or (head_dim 128) v = the
+    token-major value view like k with vT=None: no transposed copy.  Returns (out [(B*S), H*hd], lse fp32 [B,H,s_pad])."""
     scale = scale if scale is not None else 1.0 / math.sqrt(hd)
     Hkv = kv_heads or H
     if out is None:
         out = torch.empty(q.shape[0], H * hd, dtype=BF16, device=q.device)
     if lse is None:
         lse = torch.zeros(B, H, s_pad, dtype=torch.float32, device=q.device)
+    if v is not None:
+        assert vT is None and hd == 128
+        lib.call("rv_attn_fwd_nat", q, q.stride(0), k, k.stride(0), v, v.stride(0), out, out.stride(0), lse, lens, cu, B, H, Hkv, S, s_pad, hd,
+                 int(causal), scale, lib.zeros16(q.device))
+        return out, lse
     lib.call("rv_attn_fwd_gqa", q, q.stride(0), k, k.stride(0), vT, out, out.stride(0), lse, lens, cu, B, H, Hkv, S, s_pad, hd,
              int(causal), scale, lib.zeros16(q.device))
     return out, lse
 
 
 def attn_bwd(q, k, v, o, dout, lse, B, S, H, hd, s_pad, causal, lens=None, scale=None, dq=None, dk=None, dv=None,
-             kv_heads=None, use_workspace=True, cu=None):
+             kv_heads=None, use_workspace=True, cu=None, rope=None, natural=True):
+    """rope = (cos_sin table, positions or None): dq / dk are returned as gradients of the un-rotated q / k (the rotary embedding's
+    adjoint runs in the epilogues)."""
     scale = scale if scale is not None else 1.0 / math.sqrt(hd)
     dev = q.device
     Hkv = kv_heads or H
     rows = q.shape[0]                       # B*S, or the packed row count cu[B]
+    if hd == 128 and natural:
+        delta = torch.zeros(B, H, s_pad, dtype=torch.float32, device=dev)
+        dq = torch.empty(rows, H * hd, dtype=BF16, device=dev) if dq is None else dq
+        dk = torch.empty(rows, Hkv * hd, dtype=BF16, device=dev) if dk is None else dk
+        dv = torch.empty(rows, Hkv * hd, dtype=BF16, device=dev) if dv is None else dv
+        ws = torch.empty(2 * rows * H * hd, dtype=BF16, device=dev) if (Hkv != H and use_workspace) else None
+        lib.call("rv_attn_bwd_nat", q, q.stride(0), k, k.stride(0), v, v.stride(0), o, o.stride(0), dout, dout.stride(0), lse, delta,
+                 dq, dq.stride(0), dk, dk.stride(0), dv, dv.stride(0), lens, cu, rows if cu is not None else 0, B, H, Hkv, S, s_pad, hd,
+                 int(causal), scale, ws, ws.numel() * ws.element_size() if ws is not None else 0,
+                 rope[0] if rope else None, rope[1] if rope else None, lib.zeros16(dev))
+        return dq, dk, dv
     qT = transpose_heads(q, B, S, H, hd, s_pad, cu=cu)
     kT = transpose_heads(k, B, S, Hkv, hd, s_pad, cu=cu)
     doT = transpose_heads(dout, B, S, H, hd, s_pad, cu=cu)
@@ -269,10 +337,10 @@ def attn_bwd(q, k, v, o, dout, lse, B, S, H, hd, s_pad, causal, lens=None, scale
     dv = torch.empty(rows, Hkv * hd, dtype=BF16, device=dev) if dv is None else dv
     # per-query-head dK/dV partials for the small-grid grouped-query case (the C side decides whether to use it)
     ws = torch.empty(2 * rows * H * hd, dtype=BF16, device=dev) if (Hkv != H and use_workspace) else None
-    lib.call("rv_attn_bwd_gqa", q, q.stride(0), k, k.stride(0), v, v.stride(0), o, o.stride(0), dout, dout.stride(0), qT, kT, doT,
+    lib.call("rv_attn_bwd_gqa_rope", q, q.stride(0), k, k.stride(0), v, v.stride(0), o, o.stride(0), dout, dout.stride(0), qT, kT, doT,
              lse, delta, dq, dq.stride(0), dk, dk.stride(0), dv, dv.stride(0), lens, cu, rows if cu is not None else 0, B, H, Hkv, S,
              s_pad, hd, int(causal), scale,
-             ws, ws.numel() * ws.element_size() if ws is not None else 0, lib.zeros16(dev))
+             ws, ws.numel() * ws.element_size() if ws is not None else 0, rope[0] if rope else None, rope[1] if rope else None, lib.zeros16(dev))
     return dq, dk, dv
 
 

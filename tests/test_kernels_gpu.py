@@ -190,6 +190,10 @@ def test_attention_fwd_bwd(ops, B, S, H, hd, causal, lens):
     vT = ops.transpose_heads(gv, B, S, H, hd, s_pad)
     lens_t = torch.tensor(lens, dtype=torch.int32, device="cuda") if lens is not None else None
     out, lse = ops.attn_fwd(gq, gk, vT, B, S, H, hd, s_pad, causal, lens=lens_t)
+    if hd == 128:       # the natural-layout kernel (no V^T copy) must give the same result up to fp32 rounding of the softmax arithmetic
+        out_n, lse_n = ops.attn_fwd(gq, gk, None, B, S, H, hd, s_pad, causal, lens=lens_t, v=gv)
+        assert relerr(out_n.float()[:, :], out.float()) < TOL and float((lse_n - lse).abs().max()) < 1e-4
+        out, lse = out_n, lse_n
     got = out.view(B, S, H, hd).transpose(1, 2)
     valid = torch.ones(B, S, dtype=torch.bool)
     if lens is not None:
@@ -208,6 +212,9 @@ def test_attention_fwd_bwd(ops, B, S, H, hd, causal, lens):
     vl = valid[:, None, :].expand(B, H, S)
     assert float((lse[..., :S].cpu()[vl] - lse_ref[vl]).abs().max()) < 2e-3
     dq, dk, dv = ops.attn_bwd(gq, gk, gv, out, dout.cuda(), lse, B, S, H, hd, s_pad, causal, lens=lens_t)
+    if hd == 128:     # the default above is the natural-layout backward; the transposed-copy kernels stay covered too
+        for a, b_ in zip((dq, dk, dv), ops.attn_bwd(gq, gk, gv, out, dout.cuda(), lse, B, S, H, hd, s_pad, causal, lens=lens_t, natural=False)):
+            assert relerr(a, b_) < TOL
     for name, gg, rr in (("dq", dq, q.grad), ("dk", dk, k.grad), ("dv", dv, v.grad)):
         e = relerr(gg.view(B, S, H, hd).transpose(1, 2).cpu().float()[vm], rr[vm])
         assert e < 2 * TOL, (name, e)
@@ -239,6 +246,8 @@ def test_attention_gqa(ops, B, S, H, Hkv, hd, lens):
     vT = ops.transpose_heads(gv, B, S, Hkv, hd, s_pad)
     lens_t = torch.tensor(lens, dtype=torch.int32, device="cuda") if lens is not None else None
     out, lse = ops.attn_fwd(gq, gk, vT, B, S, H, hd, s_pad, True, lens=lens_t, kv_heads=Hkv)
+    if hd == 128:
+        out, lse = ops.attn_fwd(gq, gk, None, B, S, H, hd, s_pad, True, lens=lens_t, kv_heads=Hkv, v=gv)
     valid = torch.ones(B, S, dtype=torch.bool)
     if lens is not None:
         for b, L in enumerate(lens):
@@ -560,3 +569,104 @@ def test_dropout_add_matches_dropout_then_add(ops):
     assert relerr(got.cpu().float(), want.cpu().float()) < TOL
     kept = ops.dropout(x, 0.25, 77) != 0
     assert torch.equal(got[~kept], y[~kept])          # dropped positions are untouched
+
+
+def _forced(kernel):
+    """Context: force the GEMM tile kernel (1 = 128x128 -> the fused entry points take their unfused fallback, 2 = 256x256 -> fused)."""
+    import contextlib
+    from radvlm_amd import lib
+
+    @contextlib.contextmanager
+    def cm():
+        l = lib.load()
+        l.rv_gemm_select_kernel(kernel)
+        try:
+            yield
+        finally:
+            l.rv_gemm_select_kernel(0)
+    return cm()
+
+
+@pytest.mark.parametrize("M,H,Hkv,hd,bias,explicit_pos", [(700, 4, 2, 128, False, False), (1030, 2, 2, 128, True, True), (520, 6, 2, 64, True, False),
+                                                          (256, 3, 1, 128, False, True)])
+def test_gemm_rope_fused_is_bit_identical_to_gemm_then_rope(ops, M, H, Hkv, hd, bias, explicit_pos):
+    """q|k|v projection with the rotary embedding in the GEMM epilogue (B rows staged so that the partners e, e + hd/2 share a lane)
+    against the unfused sequence (GEMM, bf16 store, rope kernel) -- bit for bit, and against the oracle's apply_rope."""
+    from oracle import llava_oracle as O
+    d, kvd, K, S = H * hd, Hkv * hd, 192, 211
+    N = d + 2 * kvd
+    x, w = rnd(301, (M, K), 1.0).cuda(), rnd(302, (N, K), 0.2).cuda()
+    b = rnd(303, (N,), 0.5).cuda() if bias else None
+    cs = ops.rope_table(S, hd, 10000.0, "cuda")
+    pos = (torch.arange(M, dtype=torch.int32) * 7 % S).cuda() if explicit_pos else None
+    with _forced(1):
+        ref = ops.gemm_rope(x, w, cs, S, H + Hkv, hd, bias=b, positions=pos)
+    with _forced(2):
+        got = ops.gemm_rope(x, w, cs, S, H + Hkv, hd, bias=b, positions=pos)
+    assert torch.equal(got, ref)
+    # oracle: fp32 projection, bf16 store, half-split rotation with bf16-rounded cos / sin
+    y = (x.float().cpu() @ w.float().cpu().t() + (b.float().cpu() if bias else 0)).to(torch.bfloat16).float()
+    p = pos.cpu().long() if explicit_pos else torch.arange(M) % S
+    cos, sin = O.rope_cos_sin(S, hd)
+    cos, sin = cos.to(torch.bfloat16).float()[p], sin.to(torch.bfloat16).float()[p]
+    heads = y[:, :d + kvd].view(M, H + Hkv, hd)
+    rot = heads * cos[:, None] + O.rotate_half(heads) * sin[:, None]
+    assert relerr(got[:, :d + kvd], rot.reshape(M, -1)) < TOL
+    assert relerr(got[:, d + kvd:], y[:, d + kvd:]) < TOL                     # the v columns pass through unrotated
+
+
+@pytest.mark.parametrize("M,F,K", [(700, 448, 256), (512, 1024, 128), (1300, 200, 320)])
+def test_gemm_swiglu_fused_is_bit_identical_to_the_unfused_sequence(ops, M, F, K):
+    """gate|up projection + SwiGLU in one launch, and down_proj's input gradient + SwiGLU backward in one launch, against GEMM ->
+    bf16 store -> elementwise kernel (bit for bit; those are checked against the oracle in test_swiglu_gelu)."""
+    x, wgu = rnd(311, (M, K), 1.0).cuda(), rnd(312, (2 * F, K), 0.1).cuda()
+    with _forced(1):
+        gu_ref, act_ref = ops.gemm_swiglu_fwd(x, wgu, F)
+    with _forced(2):
+        gu, act = ops.gemm_swiglu_fwd(x, wgu, F)
+    assert torch.equal(gu, gu_ref) and torch.equal(act, act_ref)
+    assert torch.equal(gu_ref, ops.gemm_nt(x, wgu)) and torch.equal(act_ref, ops.swiglu_fwd(gu_ref, F))
+    d = 136
+    dy, wd = rnd(313, (M, d), 1.0).cuda(), rnd(314, (d, F), 0.1).cuda()
+    with _forced(1):
+        dgu_ref = ops.gemm_swiglu_bwd(dy, wd, gu, F)
+    with _forced(2):
+        dgu = ops.gemm_swiglu_bwd(dy, wd, gu, F)
+    assert torch.equal(dgu, dgu_ref)
+    assert torch.equal(dgu_ref, ops.swiglu_bwd(ops.gemm(dy, wd, tb=True), gu, F))
+
+
+@pytest.mark.parametrize("H,Hkv,hd,packed", [(4, 4, 128, False), (4, 2, 64, False), (6, 2, 128, True)])
+def test_attention_backward_with_the_rope_adjoint_in_its_epilogue(ops, H, Hkv, hd, packed):
+    """rv_attn_bwd_gqa_rope: dQ / dK un-rotated in the attention backward's epilogues == attention backward, bf16 store, then the rope
+    kernel with direction -1 (bit for bit on the register-accumulating dK/dV shape; the per-query-head + group-sum shape sums before it
+    un-rotates, which only moves bf16 rounding points)."""
+    lens = [200, 77, 130]
+    B, S = len(lens), max(lens)
+    d, kvd, s_pad = H * hd, Hkv * hd, (max(lens) + 63) // 64 * 64
+    if packed:
+        rows = sum(lens)
+        cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32).cuda()
+        pos = torch.cat([torch.arange(n, dtype=torch.int32) for n in lens]).cuda()
+        lens_t = None
+    else:
+        rows, cu, pos = B * S, None, None
+        lens_t = torch.tensor(lens, dtype=torch.int32).cuda()
+    qkv = rnd(321, (rows, d + 2 * kvd), 1.0).cuda()
+    dout = rnd(322, (rows, d), 1.0).cuda()
+    if not packed:
+        for b, n in enumerate(lens):
+            dout.view(B, S, d)[b, n:] = 0
+    q, k, v = qkv[:, :d], qkv[:, d:d + kvd], qkv[:, d + kvd:]
+    vT = ops.transpose_heads(v, B, S, Hkv, hd, s_pad, cu=cu)
+    out, lse = ops.attn_fwd(q, k, vT, B, S, H, hd, s_pad, True, lens=lens_t, kv_heads=Hkv, cu=cu)
+    cs = ops.rope_table(S, hd, 10000.0, "cuda")
+    kw = dict(lens=lens_t, kv_heads=Hkv, cu=cu)
+    dq0, dk0, dv0 = ops.attn_bwd(q, k, v, out, dout, lse, B, S, H, hd, s_pad, True, use_workspace=False, **kw)
+    ops.rope_inplace(dq0, cs, S, H, hd, 1, -1, positions=pos)
+    ops.rope_inplace(dk0, cs, S, Hkv, hd, 1, -1, positions=pos)
+    dq1, dk1, dv1 = ops.attn_bwd(q, k, v, out, dout, lse, B, S, H, hd, s_pad, True, use_workspace=False, rope=(cs, pos), **kw)
+    assert torch.equal(dq1, dq0) and torch.equal(dk1, dk0) and torch.equal(dv1, dv0)
+    if Hkv != H:
+        dq2, dk2, dv2 = ops.attn_bwd(q, k, v, out, dout, lse, B, S, H, hd, s_pad, True, use_workspace=True, rope=(cs, pos), **kw)
+        assert torch.equal(dq2, dq0) and relerr(dk2, dk0) < TOL and relerr(dv2, dv0) < TOL

@@ -16,16 +16,20 @@ from radvlm_amd.build_id import kernel_source_sha256  # noqa: E402
 path, out = sys.argv[1], sys.argv[2]
 disp = defaultdict(dict)
 name = {}
+gridsz = {}
 with open(path) as f:
     for r in csv.DictReader(f):
         d = r["Dispatch_Id"]
         disp[d][r["Counter_Name"]] = float(r["Counter_Value"])
         disp[d]["_ns"] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
         name[d] = r["Kernel_Name"]
+        gridsz[d] = r["Grid_Size"]
 fam = defaultdict(lambda: defaultdict(float))
 for d, c in disp.items():
     n = name[d]
     m = re.search(r"(gemm_kernel_256<[^>]*>|gemm_nt_kernel|attn_\w+_kernel<[^>]*>|adamw_kernel|swiglu_\w+_kernel|rmsnorm_\w+_kernel)", n)
+    if m and m.group(1).startswith("attn_"):        # attention: keep the launch shapes apart (grid size tells the sequence length)
+        m = re.match(r"(.*)", m.group(1) + " grid=" + str(gridsz[d]))
     if not m:
         continue
     k = m.group(1)
@@ -46,11 +50,12 @@ for k, c in sorted(fam.items(), key=lambda kv: -kv[1]["_ns"]):
         for key in ("GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", "_ns", "launches"):
             tot[key] += c[key]
 cyc = tot["GRBM_GUI_ACTIVE"] / 8.0
-res["gemm_kernel_256_all_forms"] = dict(launches=int(tot["launches"]), total_ms=tot["_ns"] / 1e6, clock_ghz=cyc / tot["_ns"],
-                                        mfma_busy_frac=tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0),
-                                        mfma_busy_frac_of_2p4ghz=tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (tot["_ns"] * 2.4 * 1024.0))
+if tot["_ns"] > 0:
+    res["gemm_kernel_256_all_forms"] = dict(launches=int(tot["launches"]), total_ms=tot["_ns"] / 1e6, clock_ghz=cyc / tot["_ns"],
+                                            mfma_busy_frac=tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0),
+                                            mfma_busy_frac_of_2p4ghz=tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (tot["_ns"] * 2.4 * 1024.0))
 json.dump(res, open(out, "w"), indent=1)
-print(json.dumps(res["gemm_kernel_256_all_forms"]))
+print(json.dumps(res.get("gemm_kernel_256_all_forms")))
 for k, e in res["kernels"].items():
     print(f"{k:48s} n={e['launches']:5d} {e['total_ms']:8.1f} ms clk {e['clock_ghz']:.2f} GHz mfma {e['mfma_busy_frac']:.3f} "
           f"active {e['wave_active_frac']:.2f} issue-stall {e['wave_issue_stall_frac']:.2f} parked {e['wave_parked_frac']:.2f}")
