@@ -40,6 +40,7 @@ struct GemmParams {
     //   EPI_SWIGLU_BWD  acc = d(act) [M, F]; G = gate|up [M, 2F]; C = d(gate|up) [M, 2F]
     const float* rope_cs; const int* rope_pos; int rope_S, rope_cols, rope_hd;
     int F; bf16* C2; long ldc2; const bf16* G; long ldg;
+    unsigned bytesA, bytesB;     // BUF kernels: extent of each operand = its buffer resource's num_records
 };
 enum { EPI_NONE = 0, EPI_ROPE = 1, EPI_SWIGLU_FWD = 2, EPI_SWIGLU_BWD = 3 };
 
@@ -251,6 +252,51 @@ DEVINL void stage_half(const bf16* __restrict__ src, long ld, int feat0, int nfe
         }
         glds16(g, lds + it * 1024);
     }
+}
+
+// Buffer-addressed staging (BUF kernels): the LDS-DMA is a `buffer_load_dwordx4 ... offen lds` whose address is
+//   resource base + per-lane byte offset (computed ONCE per block, loop invariant) + scalar K offset (one s_add per K-tile),
+// so a staging piece costs an M0 write and the load itself -- the flat form spent a 64-bit vector add, a range compare and two selects
+// per piece (the zero-page source select) in front of every one of the 8 pieces a wave issues per K-tile.  Rows past the end of the
+// operand (tile edges, K tails of contraction-major operands) are out of the resource's range and read as zero in hardware.
+// Requirements checked on the host: operand extent < 2 GiB; for a row-major operand K % 64 == 0 (a K tail inside a row is not a
+// resource boundary), otherwise the flat path runs.
+struct HalfPlan { int v[2]; };
+template <bool T, bool PERM, int BMAP>
+DEVINL HalfPlan plan_half(long ld, int feat0, int nfeat, int wid, int lane, int h, int F, unsigned limit) {
+    HalfPlan pl;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int it = i * 8 + wid;
+        const int c = it * 64 + lane;
+        long off;
+        bool ok = true;
+        if (!T) {
+            const int r = c >> 3, p = c & 7;
+            const int lc = p ^ ((r >> 1) & 7);
+            long gr = feat0 + (PERM ? perm32f(r) : r);
+            if (BMAP == 1) { const int f = perm32f(r); gr = feat0 + ((f & 31) | ((f & 32) << 1) | ((f & 64) >> 1)); }
+            else if (BMAP == 2) {
+                const int cc = h * 128 + perm32f(r);
+                const int f = feat0 + 32 * (cc >> 6) + (cc & 31);
+                gr = (long)((cc >> 5) & 1) * F + f;
+                ok = f < F;
+            }
+            off = (gr * ld + lc * 8) * 2;
+        } else {
+            const int r = c >> 4, p = c & 15;
+            const int lc = p ^ tswz(r);
+            off = ((long)r * ld + feat0 + lc * 8) * 2;
+            ok = feat0 + lc * 8 < nfeat;
+        }
+        pl.v[i] = (ok && off < (long)limit) ? (int)off : (int)limit;      // `limit` = the resource size: always out of range -> zero
+    }
+    return pl;
+}
+DEVINL void stage_half_buf(__amdgpu_buffer_rsrc_t rsrc, const HalfPlan& pl, int soff, char* lds, int wid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + (i * 8 + wid) * 1024), 16, pl.v[i], soff, 0, 0);
 }
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -672,7 +718,7 @@ extern "C" int rv_debug_set_stamp_buffer(void* p) { g_stamp_host = (long long*)p
 #define RV_STAMP(i) do { } while (0)
 #endif
 
-template <bool TA, bool TB, int MODE, int EPI = EPI_NONE>
+template <bool TA, bool TB, int MODE, int EPI = EPI_NONE, bool BUF = false>
 __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wid = wave_id(), lane = lane_id();
@@ -707,13 +753,31 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
     const int nt1 = (P.K + BK - 1) / BK;
     const int t0 = sliced ? (int)((long)kslice * nt1 / P.splits) : 0;
     const int nt = sliced ? (int)((long)(kslice + 1) * nt1 / P.splits) - t0 : (MODE == 1 ? nt1 + (P.K2 + BK - 1) / BK : nt1);
+    // BUF: resources + per-lane offsets of this block's staging pieces (loop invariant)
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    HalfPlan plA[2], plB[2];
+    if constexpr (BUF) {
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, P.bytesA, 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, P.bytesB, 0x00020000);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            plA[h] = plan_half<TA, false, 0>(P.lda, m0 + h * 128, P.M, wid, lane, h, 0, P.bytesA);
+            if (EPI == EPI_ROPE) plB[h] = P.rope_hd == 128 ? plan_half<TB, true, 1>(P.ldb, n0 + h * 128, P.N, wid, lane, h, 0, P.bytesB)
+                                                            : plan_half<TB, true, 0>(P.ldb, n0 + h * 128, P.N, wid, lane, h, 0, P.bytesB);
+            else if (EPI == EPI_SWIGLU_FWD) plB[h] = plan_half<TB, true, 2>(P.ldb, tn * 128, P.N, wid, lane, h, P.F, P.bytesB);
+            else plB[h] = plan_half<TB, true, 0>(P.ldb, n0 + h * 128, P.N, wid, lane, h, 0, P.bytesB);
+        }
+    }
+    const int kstepA = TA ? (int)(P.lda * BK * 2) : BK * 2, kstepB = TB ? (int)(P.ldb * BK * 2) : BK * 2;    // bytes per K-tile
     auto stageA = [&](int t, int slot, int h) {
         char* dst = smem + (slot * 2 + h) * HALF_BYTES;
+        if constexpr (BUF) { stage_half_buf(rsA, plA[h], (t0 + t) * kstepA, dst, wid); return; }
         if (MODE == 1 && t >= nt1) stage_half<TA>(P.A2, P.lda2, m0 + h * 128, P.M, (t - nt1) * BK, P.K2, P.zeros, dst, wid, lane);
         else stage_half<TA>(P.A, P.lda, m0 + h * 128, P.M, (t0 + t) * BK, P.K, P.zeros, dst, wid, lane);
     };
     auto stageB = [&](int t, int h) {
         char* dst = smem + B_RING_OFF + ((t & 1) * 2 + h) * HALF_BYTES;
+        if constexpr (BUF) { stage_half_buf(rsB, plB[h], (t0 + t) * kstepB, dst, wid); return; }
         if (MODE == 1 && t >= nt1) stage_half<TB, true>(P.B2, P.ldb2, n0 + h * 128, P.N, (t - nt1) * BK, P.K2, P.zeros, dst, wid, lane);
         else if (EPI == EPI_ROPE) {
             if (P.rope_hd == 128) stage_half<TB, true, 1>(P.B, P.ldb, n0 + h * 128, P.N, (t0 + t) * BK, P.K, P.zeros, dst, wid, lane);
@@ -731,23 +795,37 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
 
     int aslot = 0;          // A ring slot of tile t (t % 3)
     long long dbg[4] = {0, 0, 0, 0};   // diagnostic build only (RV_STAMPS): parked-cycle accumulators; dead code otherwise
-    for (int t = 0; t < nt; ++t) {
+    // One K-tile step.  STAGE = this step issues the staging of tile t + 2 (all steps but the last two): the steady-state loop is
+    // straight-line code without the four `t + 2 < nt` branches that used to cut it into basic blocks (hipcc schedules within one).
+    auto step = [&](int t, auto stage_tag) {
+        constexpr int STAGE = decltype(stage_tag)::value;      // 1 = stage tile t + 2, 0 = do not, 2 = decide at run time (t + 2 < nt)
         const char* At = smem + (aslot * 2 + wr) * HALF_BYTES;
         const char* Bt = smem + B_RING_OFF + ((t & 1) * 2 + (wc >> 1)) * HALF_BYTES;
         const int aslot2 = aslot == 0 ? 2 : aslot - 1;   // (t + 2) % 3: the slot tile t-1 just vacated
         const int brow0 = (wc & 1) * 64;
         ktile_256<TA, TB>(acc, At, Bt, brow0, lane,
-                          [&]() { if (t + 2 < nt) stageA(t + 2, aslot2, 0); }, [&]() { if (t + 2 < nt) stageA(t + 2, aslot2, 1); },
-                          [&]() { if (t + 2 < nt) stageB(t + 2, 0); }, [&]() { if (t + 2 < nt) stageB(t + 2, 1); }, dbg);
+                          [&]() { if (STAGE == 1 || (STAGE == 2 && t + 2 < nt)) stageA(t + 2, aslot2, 0); },
+                          [&]() { if (STAGE == 1 || (STAGE == 2 && t + 2 < nt)) stageA(t + 2, aslot2, 1); },
+                          [&]() { if (STAGE == 1 || (STAGE == 2 && t + 2 < nt)) stageB(t + 2, 0); },
+                          [&]() { if (STAGE == 1 || (STAGE == 2 && t + 2 < nt)) stageB(t + 2, 1); }, dbg);
         // tile t+1 (issued during tile t-1) must have landed; the 8 loads of tile t+2 stay in flight
         RV_ACC_BEGIN();
-        if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (STAGE == 1 || (STAGE == 2 && t + 2 < nt)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         RV_ACC_END(1);
         aslot = aslot == 2 ? 0 : aslot + 1;
         RV_ACC_BEGIN();
         BAR_LGKM();   // also: every wave's A reads of tile t are complete -> the A halves of this slot may be restaged
         RV_ACC_END(2);
+    };
+    if constexpr (MODE == 1 || MODE == 2) {
+        // the two-operand-pair and split-K forms keep the single loop with run-time staging decisions: two copies of the K-tile
+        // step do not fit their register budget (they are r-wide LoRA products and small outputs, not the step's bulk)
+        for (int t = 0; t < nt; ++t) step(t, std::integral_constant<int, 2>{});
+    } else {
+        int t = 0;
+        for (; t + 2 < nt; ++t) step(t, std::integral_constant<int, 1>{});
+        for (; t < nt; ++t) step(t, std::integral_constant<int, 0>{});
     }
 #ifdef RV_STAMPS
     if (MODE == 0 && P.ws && lane == 0) {   // per wave: [mid barrier, end vmcnt, end barrier] parked cycles of the whole K loop
@@ -840,7 +918,9 @@ static int g_tail_split = 1;   // rv_gemm_select_kernel(20) disables the tail sp
 static int g_force_kernel = 0;  // 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel (RV_GEMM_KERNEL or rv_gemm_select_kernel)
 static int g_cus = 0;           // 0 = not yet queried
 static int g_reserved_cus = -1; // -1 = take RV_GEMM_RESERVED_CUS (default 0) at first use
+static int g_no_buf = 0;         // rv_gemm_select_kernel(30 / 31): buffer-addressed staging off / on (A/B measurement)
 extern "C" int rv_gemm_select_kernel(int which) {
+    if (which >= 30) { g_no_buf = which == 30; return RV_OK; }
     if (which >= 20) { g_tail_split = which - 20; return RV_OK; }
     g_force_kernel = which;
     return RV_OK;
@@ -869,13 +949,21 @@ static int cu_budget() {
     return g_cus;
 }
 
-template <bool TA, bool TB, int MODE>
+// Operand extents for the buffer-addressed kernels; false when a shape does not qualify (K tail inside a row, >= 2 GiB operand).
+static bool buf_extents(GemmParams& P, int trans_a, int trans_b) {
+    if (P.K % BK) return false;
+    const long ea = (trans_a ? (long)P.K : (long)P.M) * P.lda * 2, eb = (trans_b ? (long)P.K : (long)P.N) * P.ldb * 2;
+    if (ea >= (1L << 31) || eb >= (1L << 31) || g_no_buf) return false;
+    P.bytesA = (unsigned)ea; P.bytesB = (unsigned)eb;
+    return true;
+}
+template <bool TA, bool TB, int MODE, bool BUF = false>
 static void launch256m(const GemmParams& P, hipStream_t st) {
     static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute((const void*)gemm_kernel_256<TA, TB, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2); set = true; }
+    if (!set) { (void)hipFuncSetAttribute((const void*)gemm_kernel_256<TA, TB, MODE, EPI_NONE, BUF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2); set = true; }
     const int nwg = P.tiles_m * P.tiles_n;
     const int blocks = MODE == 2 ? nwg * P.splits : (MODE == 3 ? P.n_full + (nwg - P.n_full) * P.splits : nwg);
-    hipLaunchKernelGGL((gemm_kernel_256<TA, TB, MODE>), dim3(blocks), dim3(512), LDS_BYTES2, st, P);
+    hipLaunchKernelGGL((gemm_kernel_256<TA, TB, MODE, EPI_NONE, BUF>), dim3(blocks), dim3(512), LDS_BYTES2, st, P);
     if (MODE == 3) hipLaunchKernelGGL(tail_reduce_kernel, dim3((nwg - P.n_full) * 32), dim3(256), 0, st, P);
     if (MODE == 2) {
         const long total = (long)P.M * P.N;
@@ -883,9 +971,10 @@ static void launch256m(const GemmParams& P, hipStream_t st) {
     }
 }
 template <bool TA, bool TB>
-static void launch256(const GemmParams& P, int mode, hipStream_t st) {
+static void launch256(GemmParams& P, int mode, hipStream_t st) {
     if (mode == 1) launch256m<TA, TB, 1>(P, st);
     else if (mode == 2) launch256m<TA, TB, 2>(P, st);
+    else if (buf_extents(P, TA, TB)) { if (mode == 3) launch256m<TA, TB, 3, true>(P, st); else launch256m<TA, TB, 0, true>(P, st); }
     else if (mode == 3) launch256m<TA, TB, 3>(P, st);
     else launch256m<TA, TB, 0>(P, st);
 }
@@ -977,13 +1066,18 @@ extern "C" int rv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_
 // Fused-epilogue entry points (256x256 kernel, plain tiles).  Each falls back to the unfused sequence (GEMM, then the elementwise
 // kernel of ops.hip) when the output has too few 256x256 tiles for that kernel to be the right choice, or when a shape constraint of
 // the fused form does not hold -- results are bit-identical either way (the fused epilogues keep the unfused rounding points).
+template <int EPI, bool TB, bool BUF>
+static void launch_fused1(const GemmParams& P, hipStream_t st) {
+    static bool attr = false;      // once per instantiation (see the launch-configuration note above)
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_kernel_256<false, TB, 0, EPI, BUF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2); attr = true; }
+    hipLaunchKernelGGL((gemm_kernel_256<false, TB, 0, EPI, BUF>), dim3(P.tiles_m * P.tiles_n), dim3(512), LDS_BYTES2, st, P);
+}
 template <int EPI, bool TB>
 static int launch_fused(GemmParams& P, int tiles_m, int tiles_n, hipStream_t st) {
-    static bool attr = false;      // once per instantiation (see the launch-configuration note above)
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_kernel_256<false, TB, 0, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2); attr = true; }
     P.tiles_m = tiles_m; P.tiles_n = tiles_n; P.n_full = 0; P.splits = 1; P.ws = nullptr;
     P.A2 = nullptr; P.B2 = nullptr; P.K2 = 0; P.lda2 = P.ldb2 = 0;
-    hipLaunchKernelGGL((gemm_kernel_256<false, TB, 0, EPI>), dim3(tiles_m * tiles_n), dim3(512), LDS_BYTES2, st, P);
+    if (buf_extents(P, 0, TB)) launch_fused1<EPI, TB, true>(P, st);
+    else launch_fused1<EPI, TB, false>(P, st);
     return rv_check_launch();
 }
 static bool big_enough_for_256(int M, int N) {

@@ -13,8 +13,9 @@ for k in ("A", "B"):
 z = torch.zeros(64, dtype=torch.uint8, device="cuda")
 T = 22528
 CASES = [("sq4096", 4096, 4096, 4096, 0, 0), ("sq8192", 8192, 8192, 8192, 0, 0), ("qkv_fwd", T, 12288, 4096, 0, 0), ("o_fwd", T, 4096, 4096, 0, 0), ("gu_fwd", T, 22016, 4096, 0, 0), ("down_fwd", T, 4096, 11008, 0, 0),
-         ("dh2 NN", T, 4096, 22016, 0, 1), ("gu_wgrad TT", 22016, 4096, T, 1, 1), ("o_wgrad TT", 4096, 4096, T, 1, 1), ("vit_fc1", 18464, 4096, 1024, 0, 0),
-         ("vit_out", 18464, 1024, 1024, 0, 0)]
+         ("head_fwd", T, 32000, 4096, 0, 0), ("dh2 NN", T, 4096, 22016, 0, 1), ("dact NN", T, 11008, 4096, 0, 1), ("gu_wgrad TT", 22016, 4096, T, 1, 1),
+         ("down_wgrad TT", 4096, 11008, T, 1, 1), ("o_wgrad TT", 4096, 4096, T, 1, 1), ("qkv_wgrad TT", 12288, 4096, T, 1, 1), ("vit_fc1", 18464, 4096, 1024, 0, 0)]
+tot = {"A": 0.0, "B": 0.0}
 st = torch.cuda.current_stream().cuda_stream
 for name, m, n, k, ta, tb in CASES:
     a = torch.randn((k, m) if ta else (m, k), device="cuda", dtype=torch.bfloat16)
@@ -38,4 +39,6 @@ for name, m, n, k, ta, tb in CASES:
             e1.record(); torch.cuda.synchronize()
             best[key] = min(best[key], e0.elapsed_time(e1) / 5)
     fl = 2.0 * m * n * k
+    tot["A"] += best["A"]; tot["B"] += best["B"]
     print(f"{name:14s} A {fl/best['A']/1e9:7.1f} TF/s   B {fl/best['B']/1e9:7.1f} TF/s   B/A {best['A']/best['B']:.3f}", flush=True)
+print(f"sum of times: A {tot['A']:.2f} ms  B {tot['B']:.2f} ms  B/A speed {tot['A']/tot['B']:.3f}")
