@@ -259,6 +259,14 @@ int rv_max4_rows_fwd(const void* src, int64_t ld_src, const int32_t* idx4, const
 int rv_max4_rows_bwd(const void* dout, int64_t ld_dout, const int32_t* idx4, const int32_t* dout_row, int n, const uint8_t* which,
                      void* dsrc, int64_t ld_dsrc, int d, void* stream);
 
+/* Device-side image normalisation and tiling (the host image path of train/train.py:1060-1099 + mm_utils.py:243-293 ends in
+ * processor.preprocess: rescale 1/255, (x - mean) / std, HWC -> CHW, per tile): n uint8 canvases [gh*tile, gw*tile, 3] (HOST memory is
+ * not accepted: device pointers only) -> bf16 [n*gh*gw, 3, tile, tile], tiles in row-major grid order (divide_to_patches, mm_utils.py:191-210).
+ * mode 0: CLIPImageProcessor arithmetic (float32(u8) / 255), mode 1: SigLipImageProcessor (float64(u8) * factor -> float32); mean3 / std3
+ * are HOST arrays of 3 floats (passed by value).  Bit-identical to normalising on the host in fp32 and casting on the device; the upload
+ * is a quarter of the fp32 bytes. */
+int rv_normalize_tiles_u8(const uint8_t* img, void* out, int n, int gh, int gw, int tile, int mode, double factor, const float* mean3,
+                          const float* std3, void* stream);
 /* ---- CLIP embeddings -----------------------------------------------------------------------------------------------
  * HF:modeling_clip.py:202-218: patches of pix [n,3,H,W] (bf16) -> rows [n*gh*gw, Kp], k = c*p*p + i*p + j (zero
  * padded to Kp); then out[n, 0] = cls + pos[0], out[n, 1+i] = patch_out[n, i] + pos[1+i]. */

@@ -12,6 +12,7 @@
 // accumulator registers (contraction order kappa(g,j) = 16*(2p + (j>>2)) + 4g + (j&3), matched by the A-side reads).
 //
 // Layouts: q,k,v,o,dq,dk,dv,dO are token-major rows [(b*S+s)*ld + h*HD + e]; lse/delta are fp32 [b,h,S_pad].
+#include <type_traits>
 #include "common.h"
 #include "radvlm_hip.h"
 
@@ -298,6 +299,30 @@ DEVINL void stage_nat(const bf16* src, long row_stride, int valid_rows, const bf
         glds16(g, lds + it * 1024);
     }
 }
+// Buffer-addressed staging of a natural tile: resource = this sample's rows of the operand (rows past its end read as zero in
+// hardware, also through the scalar offset), per-lane byte offsets computed once per block, scalar offset = first row of the tile
+// (+ the head's column offset): an M0 write and a `buffer_load_dwordx4 ... lds` per piece, no per-piece address arithmetic or selects.
+template <int NROWS, int NW>
+struct NatPlan {
+    int v[NROWS * 16 / 64 / NW];
+    DEVINL void init(long row_stride, int wid, int lane) {
+#pragma unroll
+        for (int i = 0; i < NROWS * 16 / 64 / NW; ++i) {
+            const int c = (i * NW + wid) * 64 + lane;
+            const int r = c >> 4, pch = c & 15;
+            v[i] = (int)(((long)r * row_stride + (pch ^ nswz(r)) * 8) * 2);
+        }
+    }
+    DEVINL void stage(__amdgpu_buffer_rsrc_t rsrc, int soff, char* lds, int wid) const {
+#pragma unroll
+        for (int i = 0; i < NROWS * 16 / 64 / NW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + (i * NW + wid) * 1024), 16, v[i], soff, 0, 0);
+    }
+};
+DEVINL __amdgpu_buffer_rsrc_t rows_rsrc(const bf16* base, long rows, long row_stride) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (unsigned)(rows * row_stride * 2), 0x00020000);
+}
+
 DEVINL void rdrow_asm(bf16x8& dst, const char* tile, int row, int chunk) {
     const unsigned o = lds_off(tile + row * 256 + ((chunk ^ nswz(row)) << 4));
     asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(o) : "memory");
@@ -346,8 +371,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
     const int kv_end = CAUSAL ? min(len, qblk * 128 + 128) : len;
     const int ntiles = (kv_end + 63) >> 6;
     const int hk = h / P.nrep;
-    const bf16* kbase = P.k + rb * P.ld_k + hk * HD;
-    const bf16* vbase = P.v + rb * P.ld_v + hk * HD;
+    // staging: buffer resources over this sample's rows (rows >= S read as zero), loop-invariant lane offsets, scalar tile offset
+    const __amdgpu_buffer_rsrc_t rsK = rows_rsrc(P.k + rb * P.ld_k, S, P.ld_k), rsV = rows_rsrc(P.v + rb * P.ld_v, S, P.ld_v);
+    NatPlan<64, 4> plK, plV;
+    plK.init(P.ld_k, wid, lane);
+    plV.init(P.ld_v, wid, lane);
+    const int kstep = (int)(64 * P.ld_k * 2), vstep = (int)(64 * P.ld_v * 2), hoff = hk * HD * 2;
 
     float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
     f32x4 o[2][DB];
@@ -356,22 +385,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
 #pragma unroll
         for (int db = 0; db < DB; ++db) o[qs][db] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    stage_nat<64, 4>(kbase, P.ld_k, S, P.zeros, smem, wid, lane);
-    stage_nat<64, 4>(vbase, P.ld_v, S, P.zeros, smem + TILE, wid, lane);
+    plK.stage(rsK, hoff, smem, wid);
+    plV.stage(rsV, hoff, smem + TILE, wid);
 
-    for (int t = 0; t < ntiles; ++t) {
+    // One key tile.  INTERIOR tiles lie wholly below the diagonal of every wave of the block and inside the sample: no mask is
+    // evaluated, no wave skips, the next tile always exists -- straight-line code.  The (at most two + one partial) tiles at the
+    // diagonal / end of the sample take the general form.
+    auto tile = [&](int t, auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const char* Kt = smem + (t & 1) * STAGE;
         const char* Vt = Kt + TILE;
-        if (t + 1 < ntiles) {
+        if (INTERIOR || t + 1 < ntiles) {
             char* nx = smem + ((t + 1) & 1) * STAGE;
-            const int kv1 = (t + 1) * 64;
-            stage_nat<64, 4>(kbase + (long)kv1 * P.ld_k, P.ld_k, S - kv1, P.zeros, nx, wid, lane);
-            stage_nat<64, 4>(vbase + (long)kv1 * P.ld_v, P.ld_v, S - kv1, P.zeros, nx + TILE, wid, lane);
+            plK.stage(rsK, (t + 1) * kstep + hoff, nx, wid);
+            plV.stage(rsV, (t + 1) * vstep + hoff, nx + TILE, wid);
         }
         const int kv0 = t * 64;
-        if (CAUSAL && kv0 > q0 + 31) continue;  // every key of this tile is in the future of this wave's rows
+        if (!INTERIOR && CAUSAL && kv0 > q0 + 31) return;  // every key of this tile is in the future of this wave's rows
 
         f32x4 s[2][4];
 #pragma unroll
@@ -411,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
         issue_v(0, vq[0]);
         issue_v(1, vq[1]);
         // lane holds S^T[key = kv0 + 16kb + 4g + r][q = q0 + 16qs + c]
-        const bool edge = (kv0 + 64 > len) || (CAUSAL && kv0 + 63 > q0);     // wave-uniform: some score of this tile may be masked
+        const bool edge = !INTERIOR && ((kv0 + 64 > len) || (CAUSAL && kv0 + 63 > q0));     // wave-uniform
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
             if (edge) {
@@ -470,7 +502,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-    }
+    };
+    // interior tiles: below the block's first query row (causal) and wholly inside the sample; never the last tile
+    const int n_int = min(CAUSAL ? min(qblk * 2, len >> 6) : (len >> 6), ntiles - 1);
+    int t = 0;
+    for (; t < n_int; ++t) tile(t, std::true_type{});
+    for (; t < ntiles; ++t) tile(t, std::false_type{});
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs) {
         float lt = l[qs];
@@ -531,8 +568,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dq_nat_kernel(AttnPa
     const int kv_end = CAUSAL ? min(len, (qblk + 1) * (32 * NW)) : len;
     const int ntiles = (kv_end + 63) >> 6;
     const int hk = h / P.nrep;
-    const bf16* kbase = P.k + rb * P.ld_k + hk * HD;
-    const bf16* vbase = P.v + rb * P.ld_v + hk * HD;
+    const __amdgpu_buffer_rsrc_t rsK = rows_rsrc(P.k + rb * P.ld_k, S, P.ld_k), rsV = rows_rsrc(P.v + rb * P.ld_v, S, P.ld_v);
+    NatPlan<64, NW> plK, plV;
+    plK.init(P.ld_k, wid, lane);
+    plV.init(P.ld_v, wid, lane);
+    const int kstep = (int)(64 * P.ld_k * 2), vstep = (int)(64 * P.ld_v * 2), hoff = hk * HD * 2;
 
     f32x4 dq[2][DB];
 #pragma unroll
@@ -540,22 +580,24 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dq_nat_kernel(AttnPa
 #pragma unroll
         for (int db = 0; db < DB; ++db) dq[qs][db] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    stage_nat<64, NW>(kbase, P.ld_k, S, P.zeros, smem, wid, lane);
-    stage_nat<64, NW>(vbase, P.ld_v, S, P.zeros, smem + TILE, wid, lane);
+    plK.stage(rsK, hoff, smem, wid);
+    plV.stage(rsV, hoff, smem + TILE, wid);
 
-    for (int t = 0; t < ntiles; ++t) {
+    // INTERIOR tiles (wholly below the block's first query row and inside the sample): no mask, no skipping wave, the next tile
+    // always exists -- straight-line code; the tiles at the diagonal / the end of the sample take the general form.
+    auto tile = [&](int t, auto interior_tag) {
+        constexpr bool INTERIOR = decltype(interior_tag)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const char* Kt = smem + (t & 1) * STAGE;
         const char* Vt = Kt + TILE;
-        if (t + 1 < ntiles) {
+        if (INTERIOR || t + 1 < ntiles) {
             char* nx = smem + ((t + 1) & 1) * STAGE;
-            const int kv1 = (t + 1) * 64;
-            stage_nat<64, NW>(kbase + (long)kv1 * P.ld_k, P.ld_k, S - kv1, P.zeros, nx, wid, lane);
-            stage_nat<64, NW>(vbase + (long)kv1 * P.ld_v, P.ld_v, S - kv1, P.zeros, nx + TILE, wid, lane);
+            plK.stage(rsK, (t + 1) * kstep + hoff, nx, wid);
+            plV.stage(rsV, (t + 1) * vstep + hoff, nx + TILE, wid);
         }
         const int kv0 = t * 64;
-        if (CAUSAL && kv0 > q0 + 31) continue;
+        if (!INTERIOR && CAUSAL && kv0 > q0 + 31) return;
 
         f32x4 s[2][4], dp[2][4];
 #pragma unroll
@@ -595,7 +637,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dq_nat_kernel(AttnPa
             for (int u = 0; u < 4; ++u) rdcol_asm(kc[u], Kt, kp, db0 + u, lane);
         };
         issue_c(0);
-        const bool edge = (kv0 + 64 > len) || (CAUSAL && kv0 + 63 > q0);
+        const bool edge = !INTERIOR && ((kv0 + 64 > len) || (CAUSAL && kv0 + 63 > q0));
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
             const int qidx = q0 + qs * 16 + c;
@@ -634,7 +676,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dq_nat_kernel(AttnPa
                 for (int qs = 0; qs < 2; ++qs) dq[qs][db0 + u] = mfma16(ktf[u], dsf[kp][qs], dq[qs][db0 + u]);
             __builtin_amdgcn_sched_barrier(0);
         }
-    }
+    };
+    const int n_int = min(CAUSAL ? min(qblk * (NW / 2), len >> 6) : (len >> 6), ntiles - 1);
+    int t = 0;
+    for (; t < n_int; ++t) tile(t, std::true_type{});
+    for (; t < ntiles; ++t) tile(t, std::false_type{});
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs) {
         const int qidx = q0 + qs * 16 + c;
@@ -683,15 +729,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dkv_nat_kernel(AttnP
 #pragma unroll
     for (int db = 0; db < DB; ++db) { dv[db] = f32x4{0.f, 0.f, 0.f, 0.f}; dk[db] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
+    const __amdgpu_buffer_rsrc_t rsQ = rows_rsrc(P.q + rb * P.ld_q, S, P.ld_q), rsO = rows_rsrc(P.dout + rb * P.ld_do, S, P.ld_do);
+    NatPlan<64, NW> plQ, plO;
+    plQ.init(P.ld_q, wid, lane);
+    plO.init(P.ld_do, wid, lane);
     auto stage = [&](int it, char* dst) {
         const int hq = h * P.qrep + it / nt;
         const int qt0 = (t0 + it % nt) * 64;
-        const bf16* qbase = P.q + rb * P.ld_q + hq * HD;
-        const bf16* dobase = P.dout + rb * P.ld_do + hq * HD;
         const float* lsebase = P.lse + (long)(b * P.H + hq) * P.S_pad;
         const float* dlbase = P.delta + (long)(b * P.H + hq) * P.S_pad;
-        stage_nat<64, NW>(qbase + (long)qt0 * P.ld_q, P.ld_q, S - qt0, P.zeros, dst, wid, lane);
-        stage_nat<64, NW>(dobase + (long)qt0 * P.ld_do, P.ld_do, S - qt0, P.zeros, dst + TILE, wid, lane);
+        plQ.stage(rsQ, (int)((long)qt0 * P.ld_q * 2) + hq * HD * 2, dst, wid);
+        plO.stage(rsO, (int)((long)qt0 * P.ld_do * 2) + hq * HD * 2, dst + TILE, wid);
         if (wid == 0) {   // lse / delta of the tile's 64 query rows ride the same LDS-DMA stream
             const float* gp = lane < 16 ? lsebase + qt0 + lane * 4 : (lane < 32 ? dlbase + qt0 + (lane - 16) * 4 : (const float*)P.zeros);
             glds16(gp, dst + 2 * TILE);
@@ -1135,6 +1183,17 @@ extern "C" int rv_attn_fwd_gqa(const void* q, int64_t ld_q, const void* k, int64
 #undef LAUNCH_FWD
     return rv_check_launch();
 }
+
+// explicit instantiations (hipcc left the host stub of one internal-linkage instantiation undefined when it was only named inside a
+// launch macro next to a generic lambda)
+namespace {
+template __global__ void attn_fwd_nat_kernel<true>(AttnParams);
+template __global__ void attn_fwd_nat_kernel<false>(AttnParams);
+template __global__ void attn_bwd_dq_nat_kernel<true, 8>(AttnParams);
+template __global__ void attn_bwd_dq_nat_kernel<false, 8>(AttnParams);
+template __global__ void attn_bwd_dkv_nat_kernel<true, 8>(AttnParams);
+template __global__ void attn_bwd_dkv_nat_kernel<false, 8>(AttnParams);
+}  // namespace
 
 extern "C" int rv_attn_fwd_nat(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v, void* out, int64_t ld_o,
                                float* lse, const int32_t* lens, const int32_t* cu_rows, int B, int H, int H_kv, int S, int S_pad, int HD,

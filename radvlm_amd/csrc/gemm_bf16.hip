@@ -195,6 +195,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams P) {
 // Both B sub-tiles stay in registers, so the B slot of tile t is free after ph2 (reused by B(t+2) in ph3/ph4); the A slot
 // of tile t-1 is free after the end barrier (reused by A(t+2)).  Every load is issued >= one K-tile (~2k cycles) before
 // its first use, stays in flight across both barriers (counted vmcnt + raw s_barrier, never vmcnt(0) in the loop).
+#ifndef RV_GROUP_M
+#define RV_GROUP_M 4      // tile rows per group of the block -> tile map (L2 locality; profiles/r02_gemm_tile_order_l2.json)
+#endif
 constexpr int BM2 = 256, BN2 = 256;
 constexpr int HALF_BYTES = 128 * BK * 2;      // 16 KiB
 constexpr int LDS_BYTES2 = 10 * HALF_BYTES;   // A ring: 3 tiles x 2 halves, B ring: 2 tiles x 2 halves
@@ -734,7 +737,7 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
         vtile = P.n_full + r / P.splits; kslice = r % P.splits; sliced = true;
     }
     int pid = xcd_remap(vtile, nwg);
-    constexpr int GROUP_M = 4;
+    constexpr int GROUP_M = RV_GROUP_M;
     const int per_group = GROUP_M * P.tiles_n;
     const int group = pid / per_group;
     const int first_m = group * GROUP_M;
@@ -879,7 +882,7 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(GemmParams P) {
     const int e = ((blockIdx.x & 31) * 256 + threadIdx.x) * 8;
     const int row = e >> 8, col = e & 255;
     const int pid = xcd_remap(P.n_full + tt, nwg);
-    constexpr int GROUP_M = 4;
+    constexpr int GROUP_M = RV_GROUP_M;
     const int per_group = GROUP_M * P.tiles_n;
     const int group = pid / per_group;
     const int first_m = group * GROUP_M;

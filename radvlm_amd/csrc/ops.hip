@@ -629,6 +629,29 @@ __global__ void clip_embed_kernel(const bf16* patch_out, const bf16* cls, const 
     st8(out + row * d + e, o);
 }
 
+// ------------------------------------------------------------------------------------------------ image normalisation (device side)
+// uint8 HWC canvases [n][gh*tile][gw*tile][3] -> bf16 CHW tiles [n*gh*gw][3][tile][tile], value = ((u8 rescaled) - mean[c]) / std[c] in the
+// host processors' own fp32 arithmetic (mode 0: CLIPImageProcessor float32(u8) / 255; mode 1: SigLipImageProcessor float64(u8) * factor,
+// then float32), rounded to bf16 -- bit-identical to "normalise on the host in fp32, cast on the device".
+__global__ void normalize_tiles_u8_kernel(const unsigned char* img, bf16* out, int n, int gh, int gw, int tile, int mode, double factor,
+                                          float m0, float m1, float m2, float s0, float s1, float s2) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per_tile = (long)tile * tile, total = (long)n * gh * gw * per_tile;
+    if (tid >= total) return;
+    const int x = tid % tile, y = (tid / tile) % tile;
+    const long t = tid / per_tile;
+    const int tx = t % gw, ty = (t / gw) % gh;
+    const long im = t / ((long)gw * gh);
+    const long W = (long)gw * tile;
+    const unsigned char* p = img + ((im * gh * tile + (long)ty * tile + y) * W + (long)tx * tile + x) * 3;
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = mode == 0 ? (float)p[c] / 255.0f : (float)((double)p[c] * factor);
+        out[(t * 3 + c) * per_tile + (long)y * tile + x] = f2bf((v - mean[c]) / sd[c]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ transpose
 // 64x64 tiles through LDS; out row c holds in[.., c] for r in [0, R_pad) (zeros beyond R).
 __global__ __launch_bounds__(TPB) void transpose_kernel(const bf16* in, long in_ld, long in_bs0, long in_bs1, bf16* out, long out_ld,
@@ -918,6 +941,14 @@ extern "C" int rv_im2col_patches(const void* pix, void* out, int n, int H, int W
     if (!pix || !out || n <= 0 || p <= 0 || H < p || W < p || Kp < 3 * p * p) return RV_ERR_ARG;
     const long total = (long)n * (H / p) * (W / p) * Kp;
     hipLaunchKernelGGL(im2col_kernel, dim3(nblocks(total, 256)), dim3(256), 0, ST, (const bf16*)pix, (bf16*)out, n, H, W, p, Kp);
+    return rv_check_launch();
+}
+extern "C" int rv_normalize_tiles_u8(const uint8_t* img, void* out, int n, int gh, int gw, int tile, int mode, double factor, const float* mean3,
+                                     const float* std3, void* stream) {
+    if (!img || !out || !mean3 || !std3 || n <= 0 || gh <= 0 || gw <= 0 || tile <= 0 || (mode != 0 && mode != 1)) return RV_ERR_ARG;
+    const long total = (long)n * gh * gw * tile * tile;
+    hipLaunchKernelGGL(normalize_tiles_u8_kernel, dim3(nblocks(total, 256)), dim3(256), 0, ST, img, (bf16*)out, n, gh, gw, tile, mode, factor,
+                       mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
     return rv_check_launch();
 }
 extern "C" int rv_clip_embed(const void* patch_out, const void* cls, const void* pos, void* out, int n, int P, int d, void* stream) {

@@ -55,6 +55,9 @@ class LlavaEngine:
         self.siglip = self.v.get("kind") == "siglip"
         self.has_cls = not self.siglip
         self.ln_eps = 1e-6 if self.siglip else 1e-5               # siglip_encoder.py:83 / CLIP config default
+        # per-channel statistics of the image processor (uint8 inputs are normalised on the device with them)
+        self.image_mean = (0.5, 0.5, 0.5) if self.siglip else (0.48145466, 0.4578275, 0.40821073)
+        self.image_std = (0.5, 0.5, 0.5) if self.siglip else (0.26862954, 0.26130258, 0.27577711)
         vhd = self.v["d"] // self.v["heads"]
         self.vhd_pad = vhd if vhd in (64, 128) else (64 if vhd < 64 else 128)
         assert vhd <= 128
@@ -121,6 +124,7 @@ class LlavaEngine:
         self.lora_step = 0
         self._patch_w = None
         self._rope = {}
+        self._stats = {}
         self.master = self.m = self.vv = None
         self.opt_step = 0
         self.pg = process_group
@@ -224,6 +228,17 @@ class LlavaEngine:
         if tower:
             self._patch_w = None
             self._vis_pad = {}
+
+    def _stat_buffer(self, key, B, H, s_pad):
+        """Zero-initialised fp32 [B, H, s_pad] softmax-statistics buffers (lse per layer, delta), allocated once and reused every step:
+        the kernels overwrite the valid entries, the padding entries are never written and stay zero -- no fill kernel per layer."""
+        k = (key, B, H, s_pad)
+        buf = self._stats.get(k)
+        if buf is None:
+            if len(self._stats) > 4 * self.l["layers"] + 8:      # shapes change from batch to batch with ragged data: do not hoard
+                self._stats.clear()
+            buf = self._stats[k] = torch.zeros(B, H, s_pad, dtype=torch.float32, device=self.device)
+        return buf
 
     def rope_table(self, S):
         if S not in self._rope:
@@ -492,7 +507,12 @@ class LlavaEngine:
         self.lora_step += 1
         pix = torch.cat([(im if im.ndim == 4 else im[None]) for im in images], 0)
         pix = pix.to(dev, non_blocking=True)
-        pix = pix if pix.dtype == BF16 else ops.to_bf16(pix.float())
+        if pix.dtype == torch.uint8:
+            # device-side normalisation: uint8 HWC tiles from the host (resize / crop / pad only), rescale + (x - mean) / std
+            # + channel-first layout + bf16 cast here, in the processors' own fp32 arithmetic
+            pix = ops.normalize_tiles_u8(pix.contiguous(), self.v["image"], self.image_mean, self.image_std, mode=1 if self.siglip else 0)
+        else:
+            pix = pix if pix.dtype == BF16 else ops.to_bf16(pix.float())
         ctx = dict(plan=plan)
         table = self.encode_images(pix.contiguous(), save=ctx, plan=plan)
         B = int(np.asarray(input_ids).shape[0])   # samples (a sample may hold several images: images are consumed in order)
@@ -545,7 +565,7 @@ class LlavaEngine:
                 qkv = ops.gemm_rope(h1, lv["qkv"], cs, S, H + Hkv, hd, bias=lv.get("bqkv"), positions=pos)
             if hd == 128:     # natural-layout kernel: K and V tiles are staged as they lie in memory (no V^T copy)
                 attn, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d:d + kvd], None, B, S, H, hd, s_pad, causal=True, lens=lens, kv_heads=Hkv, cu=cu,
-                                         v=qkv[:, d + kvd:])
+                                         v=qkv[:, d + kvd:], lse=self._stat_buffer(("lse", i), B, H, s_pad))
             else:
                 vT = ops.transpose_heads(qkv[:, d + kvd:], B, S, Hkv, hd, s_pad, cu=cu)
                 attn, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d:d + kvd], vT, B, S, H, hd, s_pad, causal=True, lens=lens, kv_heads=Hkv, cu=cu)
@@ -716,7 +736,7 @@ class LlavaEngine:
             # the rotary embedding's adjoint runs in the dQ / dK epilogues: dqkv = gradient of the un-rotated q|k|v projection
             ops.attn_bwd(qkv[:, :d], qkv[:, d:d + kvd], qkv[:, d + kvd:], a["attn"], dattn, a["lse"], B, S, H, hd, s_pad, True,
                          lens=lens, dq=dqkv[:, :d], dk=dqkv[:, d:d + kvd], dv=dqkv[:, d + kvd:], kv_heads=Hkv, cu=cu,
-                         rope=(cs, pos) if self.fused else None)
+                         rope=(cs, pos) if self.fused else None, delta=self._stat_buffer("delta", B, H, s_pad))
             if not self.fused:
                 ops.rope_inplace(dqkv, cs, S, H + Hkv, hd, 1, -1, positions=pos)
             if "bqkv" in gv:

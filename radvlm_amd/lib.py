@@ -80,6 +80,7 @@ _SIGS = {
     "rv_sum_f32": [_c_void_p, _i64, _f32, _c_void_p, _c_void_p],
     "rv_gather_rows": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i32, _i32, _c_void_p],
     "rv_segment_sum_rows": [_c_void_p, _i64, _c_void_p, _c_void_p, _c_void_p, _i32, _c_void_p, _i64, _i32, _c_void_p],
+    "rv_normalize_tiles_u8": [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i32, ctypes.c_double, ctypes.POINTER(_f32), ctypes.POINTER(_f32), _c_void_p],
     "rv_im2col_patches": [_c_void_p, _c_void_p, _i32, _i32, _i32, _i32, _i32, _c_void_p],
     "rv_clip_embed": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _i32, _c_void_p],
     "rv_adamw": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _i64, _f32, _f32, _f32, _f32, _f32, _f32, _f32,

@@ -49,9 +49,27 @@ class ClipImageProcessor:
     def preprocess(self, images, return_tensors="pt"):
         if not isinstance(images, (list, tuple)):
             images = [images]
+        if self.device_normalize:
+            return {"pixel_values": torch.stack([self._one_u8(im) for im in images], 0)}
         return {"pixel_values": torch.stack([self._one(im) for im in images], 0)}
 
     __call__ = preprocess
+
+    # device-side normalisation: the host stops after resize + crop and hands over uint8 HWC pixels; rescale, normalise,
+    # channel-first layout and the bf16 cast run on the GPU (rv_normalize_tiles_u8, bit-identical to _one() + cast)
+    device_normalize = False
+    normalize_mode = 0
+
+    def _one_u8(self, img):
+        img = img.convert("RGB")
+        w, h = img.size
+        s = self.size["shortest_edge"]
+        nw, nh = (s, int(s * h / w)) if w <= h else (int(s * w / h), s)
+        if (nw, nh) != (w, h):
+            img = img.resize((nw, nh), resample=Image.BICUBIC)
+        ch, cw = self.crop_size["height"], self.crop_size["width"]
+        left, top = (nw - cw) // 2, (nh - ch) // 2
+        return torch.from_numpy(np.asarray(img.crop((left, top, left + cw, top + ch)), dtype=np.uint8).copy())
 
 
 class SigLipImageProcessor:
@@ -77,9 +95,18 @@ class SigLipImageProcessor:
     def preprocess(self, images, return_tensors="pt"):
         if not isinstance(images, (list, tuple)):
             images = [images]
+        if self.device_normalize:
+            return {"pixel_values": torch.stack([self._one_u8(im) for im in images], 0)}
         return {"pixel_values": torch.stack([self._one(im) for im in images], 0)}
 
     __call__ = preprocess
+
+    device_normalize = False       # see ClipImageProcessor: uint8 HWC hand-over, normalisation on the GPU
+    normalize_mode = 1
+
+    def _one_u8(self, img):
+        h, w = self.size
+        return torch.from_numpy(np.asarray(img.convert("RGB").resize((w, h), resample=Image.BICUBIC), dtype=np.uint8).copy())
 
 
 def resize_and_pad_image(image, target_resolution):

@@ -80,6 +80,7 @@ class DataArguments:
     frames_upbound: Optional[int] = 0
     add_time_instruction: Optional[bool] = False
     force_sample: Optional[bool] = False
+    device_image_normalize: bool = False   # build-specific: the dataset hands uint8 pixels over, rescale / normalise / layout run on the GPU
 
 
 @dataclass
@@ -429,7 +430,10 @@ class LazySupervisedDataset(Dataset):
             out["image"] = image
         elif self.data_args.is_multimodal:
             cs = self.data_args.image_processor.crop_size
-            out["image"] = [(torch.zeros(1, 3, cs["height"], cs["width"]), (cs["width"], cs["height"]), "text")]
+            if getattr(self.data_args.image_processor, "device_normalize", False):      # uint8 hand-over: the dummy image too
+                out["image"] = [(torch.zeros(1, cs["height"], cs["width"], 3, dtype=torch.uint8), (cs["width"], cs["height"]), "text")]
+            else:
+                out["image"] = [(torch.zeros(1, 3, cs["height"], cs["width"]), (cs["width"], cs["height"]), "text")]
         out["id"] = rec.get("id", i)
         return out
 
@@ -586,6 +590,8 @@ def train(attn_implementation=None, argv=None, tokenizer=None):
         data_args.image_processor = SigLipImageProcessor(size=(side, side), crop_size={"height": side, "width": side})
     else:
         data_args.image_processor = ClipImageProcessor(size=side)
+    data_args.image_processor.device_normalize = bool(data_args.device_image_normalize)
+    model.engine.image_mean, model.engine.image_std = tuple(data_args.image_processor.image_mean), tuple(data_args.image_processor.image_std)
     data_args.is_multimodal = True
     data_args.mm_use_im_start_end = model_args.mm_use_im_start_end
     module = make_supervised_data_module(tokenizer=tokenizer, data_args=data_args)

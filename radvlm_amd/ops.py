@@ -310,7 +310,7 @@ def attn_fwd(q, k, vT, B, S, H, hd, s_pad, causal, lens=None, scale=None, out=No
 
 
 def attn_bwd(q, k, v, o, dout, lse, B, S, H, hd, s_pad, causal, lens=None, scale=None, dq=None, dk=None, dv=None,
-             kv_heads=None, use_workspace=True, cu=None, rope=None, natural=True):
+             kv_heads=None, use_workspace=True, cu=None, rope=None, natural=True, delta=None):
     """rope = (cos_sin table, positions or None): dq / dk are returned as gradients of the un-rotated q / k (the rotary embedding's
     adjoint runs in the epilogues)."""
     scale = scale if scale is not None else 1.0 / math.sqrt(hd)
@@ -318,7 +318,7 @@ def attn_bwd(q, k, v, o, dout, lse, B, S, H, hd, s_pad, causal, lens=None, scale
     Hkv = kv_heads or H
     rows = q.shape[0]                       # B*S, or the packed row count cu[B]
     if hd == 128 and natural:
-        delta = torch.zeros(B, H, s_pad, dtype=torch.float32, device=dev)
+        delta = torch.zeros(B, H, s_pad, dtype=torch.float32, device=dev) if delta is None else delta
         dq = torch.empty(rows, H * hd, dtype=BF16, device=dev) if dq is None else dq
         dk = torch.empty(rows, Hkv * hd, dtype=BF16, device=dev) if dk is None else dk
         dv = torch.empty(rows, Hkv * hd, dtype=BF16, device=dev) if dv is None else dv
@@ -331,7 +331,7 @@ def attn_bwd(q, k, v, o, dout, lse, B, S, H, hd, s_pad, causal, lens=None, scale
     qT = transpose_heads(q, B, S, H, hd, s_pad, cu=cu)
     kT = transpose_heads(k, B, S, Hkv, hd, s_pad, cu=cu)
     doT = transpose_heads(dout, B, S, H, hd, s_pad, cu=cu)
-    delta = torch.zeros(B, H, s_pad, dtype=torch.float32, device=dev)
+    delta = torch.zeros(B, H, s_pad, dtype=torch.float32, device=dev) if delta is None else delta
     dq = torch.empty(rows, H * hd, dtype=BF16, device=dev) if dq is None else dq
     dk = torch.empty(rows, Hkv * hd, dtype=BF16, device=dev) if dk is None else dk
     dv = torch.empty(rows, Hkv * hd, dtype=BF16, device=dev) if dv is None else dv
@@ -445,6 +445,18 @@ def add_pos_rows(x, pos, n, P):
     assert x.is_contiguous() and pos.is_contiguous() and x.shape[0] == n * P and pos.shape[0] == P
     lib.call("rv_add_pos_rows", x, pos, n, P, x.shape[1])
     return x
+
+
+def normalize_tiles_u8(img, tile, mean, std, mode=0, factor=1.0 / 255, gh=1, gw=1):
+    """uint8 device canvases [n, gh*tile, gw*tile, 3] -> normalised bf16 tiles [n*gh*gw, 3, tile, tile] (host processors' fp32 arithmetic:
+    mode 0 = CLIPImageProcessor, 1 = SigLipImageProcessor)."""
+    import ctypes
+    assert img.is_cuda and img.dtype == torch.uint8 and img.is_contiguous() and img.shape[1:] == (gh * tile, gw * tile, 3), img.shape
+    n = img.shape[0]
+    out = torch.empty(n * gh * gw, 3, tile, tile, dtype=BF16, device=img.device)
+    m3, s3 = (ctypes.c_float * 3)(*[float(x) for x in mean]), (ctypes.c_float * 3)(*[float(x) for x in std])
+    lib.call("rv_normalize_tiles_u8", img, out, n, gh, gw, tile, int(mode), float(factor), m3, s3)
+    return out
 
 
 def im2col_patches(pix, p, kp):

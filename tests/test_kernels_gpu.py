@@ -670,3 +670,30 @@ def test_attention_backward_with_the_rope_adjoint_in_its_epilogue(ops, H, Hkv, h
     if Hkv != H:
         dq2, dk2, dv2 = ops.attn_bwd(q, k, v, out, dout, lse, B, S, H, hd, s_pad, True, use_workspace=True, rope=(cs, pos), **kw)
         assert torch.equal(dq2, dq0) and relerr(dk2, dk0) < TOL and relerr(dv2, dv0) < TOL
+
+
+@pytest.mark.parametrize("kind,gh,gw", [("clip", 1, 1), ("siglip", 1, 1), ("clip", 2, 3)])
+def test_device_side_image_normalisation_is_bit_identical_to_the_host_processor(ops, kind, gh, gw):
+    """rv_normalize_tiles_u8: uint8 HWC canvases -> normalised bf16 CHW tiles == the host processor's fp32 result cast to
+    bf16, bit for bit (CLIP: float32(u8) / 255; SigLIP: float64(u8) * (1/255) -> float32), incl. the row-major tile grid of
+    divide_to_patches (mm_utils.py:191-210)."""
+    from PIL import Image
+    from radvlm_amd.llava.mm_utils import ClipImageProcessor, SigLipImageProcessor
+    tile = 56
+    proc = ClipImageProcessor(tile) if kind == "clip" else SigLipImageProcessor(size=(tile, tile), crop_size={"height": tile, "width": tile})
+    rng = np.random.default_rng(5)
+    canvases = rng.integers(0, 256, size=(3, gh * tile, gw * tile, 3), dtype=np.uint8)
+    canvases[0, :4, :4] = [[[0, 255, 128]]]
+    want = []
+    for cv in canvases:
+        for ty in range(gh):
+            for tx in range(gw):
+                t = Image.fromarray(cv[ty * tile:(ty + 1) * tile, tx * tile:(tx + 1) * tile])
+                want.append(proc.preprocess(t)["pixel_values"][0])
+    want = torch.stack(want).to(torch.bfloat16)
+    got = ops.normalize_tiles_u8(torch.from_numpy(canvases).cuda(), tile, proc.image_mean, proc.image_std, mode=proc.normalize_mode, gh=gh, gw=gw)
+    assert got.shape == want.shape and torch.equal(got.cpu(), want)
+    # the processors' uint8 hand-over is exactly the canvas they would have normalised
+    proc.device_normalize = True
+    u8 = proc.preprocess(Image.fromarray(canvases[1, :tile, :tile]))["pixel_values"][0]
+    assert u8.dtype == torch.uint8 and np.array_equal(u8.numpy(), canvases[1, :tile, :tile])

@@ -251,3 +251,19 @@ def test_pretraining_stage_with_start_end_tokens_trains_the_input_embeddings(gol
         frozen = LlavaLlamaForCausalLM(LlavaConfig(geometry=GEOMETRIES["toy"], freeze_lm=True), device="cuda:0", init="fast")
         frozen.initialize_vision_tokenizer(SimpleNamespace(mm_use_im_patch_token=False, mm_use_im_start_end=True, tune_mm_mlp_adapter=True,
                                                            pretrain_mm_mlp_adapter=None), Tok())
+
+
+def test_device_image_normalisation_gives_the_same_training_run(tmp_path):
+    """--device_image_normalize True: the dataset hands uint8 pixels over and the GPU normalises them (rv_normalize_tiles_u8); losses of a
+    short run are bit-identical to the host-normalised run (same bf16 pixel tensor reaches the tower)."""
+    _need_gpu()
+    from radvlm_amd.llava import conversation as conv_lib
+    from radvlm_amd.llava.train.train import train
+    data = _dataset(tmp_path, n=4)
+    common = ["--geometry", "toy", "--max_steps", "2", "--dataloader_num_workers", "0"]
+    try:
+        a = train(argv=_train_args(tmp_path, data, common + ["--output_dir", str(tmp_path / "h")]), tokenizer=Tok())
+        b = train(argv=_train_args(tmp_path, data, common + ["--output_dir", str(tmp_path / "d"), "--device_image_normalize", "True"]), tokenizer=Tok())
+        assert [r["loss"] for r in a["log_history"]] == [r["loss"] for r in b["log_history"]]
+    finally:
+        conv_lib.default_conversation = conv_lib.conv_templates["v1"]
