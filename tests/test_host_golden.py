@@ -261,3 +261,45 @@ def test_highres_and_crop_split_image_modes(golden_dir):
         assert list(t.shape) == H["crop_split_shapes"][i]
         assert np.abs(t.numpy()[:, :, ::8, ::8] - A[f"crop_split{i}"]).max() < 2e-2
         assert np.abs(t.numpy().reshape(t.shape[0], -1).mean(1) - A[f"crop_split{i}_mean"]).max() < 2e-3
+
+
+def test_onevision_to_hf_converter_contract(golden_dir):
+    """the key renaming of the reference's LLaVA-OneVision -> HF converter (its table and function, executed from their source
+    lines on this package's Qwen2 + SigLIP key set -> host_convert_keys.json) == radvlm_amd.convert_hf, key for key; the converted names
+    are the HF LlavaOnevision parameter names."""
+    import json as _json
+    import torch
+    from oracle import llava_oracle as O
+    from radvlm_amd.config import GEOMETRIES
+    from radvlm_amd.convert_hf import convert_state_dict_to_hf, hf_key
+    g = _json.load(open(os.path.join(golden_dir, "host_convert_keys.json")))
+    for k, want in g["mapping"].items():
+        assert hf_key(k) == want, (k, hf_key(k), want)
+    for k in g["dropped"]:
+        assert hf_key(k) is None
+    keys = list(O.param_shapes(GEOMETRIES["toy_qwen"], with_newline=True))
+    assert set(keys) == set(g["mapping"])                               # the fixture covers every tensor this package writes
+    assert g["mapping"]["model.image_newline"] == "image_newline"
+    assert g["mapping"]["model.mm_projector.2.bias"] == "multi_modal_projector.linear_2.bias"
+    assert g["mapping"]["model.vision_tower.vision_tower.vision_model.encoder.layers.1.mlp.fc1.weight"] == "vision_tower.vision_model.encoder.layers.1.mlp.fc1.weight"
+    sd = {k: torch.ones(1) for k in keys if k != "lm_head.weight"}      # tied head: cloned from the embeddings like the reference does
+    out = convert_state_dict_to_hf(sd, dtype=torch.float16)
+    assert "language_model.lm_head.weight" in out and all(v.dtype == torch.float16 for v in out.values()) and len(out) == len(keys)
+
+
+def test_saved_checkpoint_is_consumable_by_the_converter(golden_dir, tmp_path):
+    """A directory written by save_pretrained holds what convert_llava_onevision_weights_to_hf.py reads: *.safetensors under LLaVA names that
+    convert onto the HF layout, and config.json naming the tower (no GPU needed: the engine's stores live on the CPU here)."""
+    import json as _json
+    from radvlm_amd.config import GEOMETRIES
+    from radvlm_amd.convert_hf import check_checkpoint_dir
+    from radvlm_amd.llava.model import LlavaQwenConfig, LlavaQwenForCausalLM
+    model = LlavaQwenForCausalLM(LlavaQwenConfig(geometry=GEOMETRIES["toy_qwen"], mm_patch_merge_type="spatial_unpad"), device="cpu", init="portable")
+    with pytest.raises(KeyError, match="mm_vision_tower"):
+        model.save_pretrained(str(tmp_path / "a"))
+        check_checkpoint_dir(str(tmp_path / "a"))
+    model.config.mm_vision_tower = "google/siglip-so400m-patch14-384"
+    model.save_pretrained(str(tmp_path / "b"))
+    got = check_checkpoint_dir(str(tmp_path / "b"))
+    want = _json.load(open(os.path.join(golden_dir, "host_convert_keys.json")))["mapping"]
+    assert sorted(got) == sorted(want.values())
