@@ -351,7 +351,9 @@ def main():
     if rank == 0:
         out = {
             "metric": ("train image-instruction pairs/sec, LLaVA-OV Qwen2-7B + SigLIP-so400m 384px anyres_max_9 (SURVEY 8f.1; not the "
-                       "BASELINE metric)" if args.workload == "radvlm" else "train image-instruction pairs/sec, LLaVA-1.5-7B 336px"),
+                       "BASELINE metric)" if args.workload == "radvlm" else
+                       ("train image-instruction pairs/sec, LLaVA-1.5-7B 336px" if args.geometry == "llava15_7b" else
+                        f"train image-instruction pairs/sec, geometry {args.geometry} (not the BASELINE metric)")),
             "value": value, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",

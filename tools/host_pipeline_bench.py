@@ -46,13 +46,18 @@ def main():
     json.dump(recs, open(os.path.join(tmp, "d.json"), "w"))
     conv_lib.default_conversation = conv_lib.conv_templates["v1"]
     out = {}
+    def u8(proc):      # device-side normalisation: the host stops after resize / crop / pad and hands uint8 pixels over
+        proc.device_normalize = True
+        return proc
     for name, proc, aspect, pin in (("llava15_pad_336", ClipImageProcessor(336), "pad", None),
-                                    ("radvlm_anyres_max_9_384", SigLipImageProcessor(), "anyres_max_9", "(1x1),...,(6x6)")):
+                                    ("llava15_pad_336_u8", u8(ClipImageProcessor(336)), "pad", None),
+                                    ("radvlm_anyres_max_9_384", SigLipImageProcessor(), "anyres_max_9", "(1x1),...,(6x6)"),
+                                    ("radvlm_anyres_max_9_384_u8", u8(SigLipImageProcessor()), "anyres_max_9", "(1x1),...,(6x6)")):
         da = DataArguments(data_path=os.path.join(tmp, "d.json"), image_folder=tmp, image_aspect_ratio=aspect, image_grid_pinpoints=pin,
                            is_multimodal=True)
         da.image_processor, da.mm_use_im_start_end = proc, False
         mod = make_supervised_data_module(tokenizer=Tok(), data_args=da)
-        for workers in (0, 4, 8, 16):
+        for workers in (0, 8, 16):
             batches = [list(range(i, i + 8)) for i in range(0, n, 8)] * 2
             p = BatchPrefetcher(mod["train_dataset"], mod["data_collator"], batches, num_workers=workers, pin=False)
             t = time.perf_counter()
@@ -61,6 +66,7 @@ def main():
             p.close()
             out[f"{name}/workers={workers}"] = round(k / dt, 1)
             print(f"{name:28s} workers={workers:2d}: {k / dt:7.1f} samples/s", flush=True)
+    out["cores"] = os.cpu_count()
     print(json.dumps(out))
 
 
