@@ -13,6 +13,7 @@
 //
 // Layouts: q,k,v,o,dq,dk,dv,dO are token-major rows [(b*S+s)*ld + h*HD + e]; lse/delta are fp32 [b,h,S_pad].
 #include <type_traits>
+#include <stdlib.h>
 #include "common.h"
 #include "radvlm_hip.h"
 
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
 // 8 waves x 32 query rows per block; per 64-key tile: S^T = K Q^T and dP^T = V dO^T from row reads, dQ^T += K^T dS^T from column
 // reads of the SAME K image (no K^T copy).  p = exp2(s * scale*log2e - lse*log2e) is one fma + one exp per score.
 template <bool CAUSAL, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dq_nat_kernel(AttnParams P) {
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_nat_kernel(AttnParams P) {
     constexpr int HD = 128, KS = 4, DB = 8, TILE = 64 * 256, STAGE = 2 * TILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wid = wave_id(), lane = lane_id(), g = lane >> 4, c = lane & 15;
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dq_nat_kernel(AttnPa
 // 8 waves x 16 keys per block; per 64-query tile: S = Q K^T and dP = dO V^T from row reads of the Q / dO images, dV^T += dO^T P and
 // dK^T += Q^T dS from column reads of the SAME images (no Q^T / dO^T copies: half the staging traffic of the transposed-copy form).
 template <bool CAUSAL, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void attn_bwd_dkv_nat_kernel(AttnParams P) {
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_nat_kernel(AttnParams P) {
     constexpr int HD = 128, KS = 4, DB = 8, TILE = 64 * 256, STAGE = 2 * TILE + 1024;   // Q | dO | lse, delta
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wid = wave_id(), lane = lane_id(), g = lane >> 4, c = lane & 15;
@@ -1191,8 +1192,8 @@ template __global__ void attn_fwd_nat_kernel<true>(AttnParams);
 template __global__ void attn_fwd_nat_kernel<false>(AttnParams);
 template __global__ void attn_bwd_dq_nat_kernel<true, 8>(AttnParams);
 template __global__ void attn_bwd_dq_nat_kernel<false, 8>(AttnParams);
-template __global__ void attn_bwd_dkv_nat_kernel<true, 8>(AttnParams);
-template __global__ void attn_bwd_dkv_nat_kernel<false, 8>(AttnParams);
+template __global__ void attn_bwd_dkv_nat_kernel<true, 4>(AttnParams);
+template __global__ void attn_bwd_dkv_nat_kernel<false, 4>(AttnParams);
 }  // namespace
 
 extern "C" int rv_attn_fwd_nat(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v, void* out, int64_t ld_o,
@@ -1297,14 +1298,14 @@ extern "C" int rv_attn_bwd_nat(const void* q, int64_t ld_q, const void* k, int64
     P.B = B; P.H = H; P.S = S; P.S_pad = S_pad; P.scale = scale; P.Hkv = H_kv; P.nrep = H / H_kv;
     P.rope_cs = rope_cos_sin; P.rope_pos = rope_positions; P.rope_dk = 1;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid_dq((S + 255) / 256, H, B), grid_dkv((S + 127) / 128, H_kv, B);
+    dim3 grid_dq((S + 255) / 256, H, B), grid_dkv((S + 63) / 64, H_kv, B);
     AttnParams PK = P;
     PK.kdiv = 1; PK.qrep = P.nrep;
     const long rows_all = cu_rows ? (long)total_rows : (long)B * S;
     if (cu_rows && total_rows <= 0) return RV_ERR_ARG;
     const int64_t need = 2 * (int64_t)rows_all * H * HD * 2;
     const bool expand = P.nrep > 1 && workspace && workspace_bytes >= need && (((uintptr_t)workspace) & 15) == 0 &&
-                        (long)grid_dkv.x * H_kv * B < 2048;
+                        (long)grid_dkv.x * H_kv * B < 4096;
     if (expand) {     // few key/value heads and a long causal sequence: per-query-head blocks + a group sum balance better
         PK.kdiv = P.nrep; PK.qrep = 1; PK.rope_dk = 0;
         PK.dk = (bf16*)workspace; PK.dv = (bf16*)workspace + (int64_t)rows_all * H * HD;
@@ -1312,12 +1313,14 @@ extern "C" int rv_attn_bwd_nat(const void* q, int64_t ld_q, const void* k, int64
         grid_dkv.y = H;
     }
     const int smem_dq = 2 * 2 * 64 * 256, smem_dkv = 2 * (2 * 64 * 256 + 1024);
+    // dK/dV pass: 4-wave blocks of 64 keys, two per CU (independent blocks hide each other's barriers and staging latency; measured
+    // against 8-wave blocks of 128 keys: -10 % at S = 704, -3 % at S = 3056, -1 % at S = 7499)
 #define LAUNCH_BWD_NAT(C_)                                                                                 \
     do {                                                                                                   \
         set_smem(attn_bwd_dq_nat_kernel<C_, 8>, smem_dq);                                                  \
-        set_smem(attn_bwd_dkv_nat_kernel<C_, 8>, smem_dkv);                                                \
+        set_smem(attn_bwd_dkv_nat_kernel<C_, 4>, smem_dkv);                                                \
         hipLaunchKernelGGL((attn_bwd_dq_nat_kernel<C_, 8>), grid_dq, dim3(512), smem_dq, st, P);           \
-        hipLaunchKernelGGL((attn_bwd_dkv_nat_kernel<C_, 8>), grid_dkv, dim3(512), smem_dkv, st, PK);       \
+        hipLaunchKernelGGL((attn_bwd_dkv_nat_kernel<C_, 4>), grid_dkv, dim3(256), smem_dkv, st, PK);       \
     } while (0)
     if (causal) LAUNCH_BWD_NAT(true); else LAUNCH_BWD_NAT(false);
 #undef LAUNCH_BWD_NAT
