@@ -346,6 +346,49 @@ template <int LEFT> DEVINL void tf_wait4(TFrag (&f)[4]) {
                  : "i"(LEFT) : "memory");
 }
 
+// Compile-time loop (the index is a constant expression inside the body: immediates of the asm reads below).
+template <int N, class F>
+DEVINL void sfor(F&& f) {
+    if constexpr (N > 0) {
+        sfor<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+// Loop-invariant read addresses of a natural tile.  Everything that depends on the lane sits in 4 registers for the row reads (one
+// per 32-dim k-step: the swizzle term depends on the row's low three bits = the lane's) and 8 for the column reads (one per 16-dim
+// block); the 16-row block, the 32-row step, the +16-row partner and the operand image inside a stage are IMMEDIATES of the read.
+// Per tile the kernels pay one add per register (stage toggle) instead of an address computation per read (was 43-69 VALU / tile).
+struct NatAddr {
+    unsigned row[4], col[8];
+    DEVINL void init(const char* image, int lane) {
+        const int g = lane >> 4, c = lane & 15, r1 = (lane >> 2) & 15, pp = lane & 3;
+        const unsigned b = lds_off(image);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) row[ks] = b + c * 256 + (((ks * 4 + g) ^ nswz(c)) << 4);
+#pragma unroll
+        for (int db = 0; db < 8; ++db) col[db] = b + r1 * 256 + (((2 * db + (pp >> 1)) ^ nswz(r1)) << 4) + ((pp & 1) << 3);
+    }
+    DEVINL void shift(int delta) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) row[i] += delta;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) col[i] += delta;
+    }
+};
+// row fragment: rows 16 kb + (lane & 15) of the image at byte offset IMG within the stage: IMM = IMG + kb * 4096
+template <int IMM> DEVINL void rdrow_imm(bf16x8& dst, unsigned a) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(a), "i"(IMM) : "memory");
+}
+// column fragment of the 32-row step p: IMM = IMG + p * 8192 (the partner rows + 16 sit 4096 bytes further, same swizzle term)
+template <int IMM> DEVINL void rdcol_imm(TFrag& f, unsigned a) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.t0) : "v"(a), "i"(IMM) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.t1) : "v"(a), "i"(IMM + 4096) : "memory");
+}
+// v_max3_f32 / v_max_f32 without the canonicalising self-maximum hipcc puts in front of every fmaxf operand that comes out of an
+// MFMA (IEEE mode: 32 extra VALU per tile).  volatile: they stay behind the volatile LDS reads issued after the MFMA chain, which
+// provide the wait states between an MFMA result and its first VALU read (the hazard recogniser does not look into inline asm).
+DEVINL float max3_asm(float a, float b, float c) { float r; asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 // ------------------------------------------------------------------------------------------------ forward (natural V)
 // Softmax arithmetic per score: one v_max, one v_fma (s * scale*log2e - m) and one v_exp; the causal / key-padding mask is only
 // evaluated on the tiles that touch the diagonal or the end of the sample.
@@ -388,6 +431,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
 
     plK.stage(rsK, hoff, smem, wid);
     plV.stage(rsV, hoff, smem + TILE, wid);
+    NatAddr ad;
+    ad.init(smem + STAGE, lane);          // the first tile's toggle brings it to stage 0
 
     // One key tile.  INTERIOR tiles lie wholly below the diagonal of every wave of the block and inside the sample: no mask is
     // evaluated, no wave skips, the next tile always exists -- straight-line code.  The (at most two + one partial) tiles at the
@@ -396,8 +441,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
         constexpr bool INTERIOR = decltype(interior_tag)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const char* Kt = smem + (t & 1) * STAGE;
-        const char* Vt = Kt + TILE;
+        ad.shift((t & 1) ? STAGE : -STAGE);
         if (INTERIOR || t + 1 < ntiles) {
             char* nx = smem + ((t + 1) & 1) * STAGE;
             plK.stage(rsK, (t + 1) * kstep + hoff, nx, wid);
@@ -413,15 +457,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
             for (int kb = 0; kb < 4; ++kb) s[qs][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
         {   // S^T = K Q^T
             bf16x8 kq[3][KS];
-            auto issue_k = [&](int kb, bf16x8 (&dst)[KS]) {
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) rdrow_asm(dst[ks], Kt, kb * 16 + c, ks * 4 + g);
+            auto issue_k = [&](auto kbt, bf16x8 (&dst)[KS]) {
+                sfor<KS>([&](auto ks) { rdrow_imm<decltype(kbt)::value * 4096>(dst[decltype(ks)::value], ad.row[decltype(ks)::value]); });
             };
-            issue_k(0, kq[0]);
-            issue_k(1, kq[1]);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                if (kb + 2 < 4) issue_k(kb + 2, kq[(kb + 2) % 3]);
+            issue_k(std::integral_constant<int, 0>{}, kq[0]);
+            issue_k(std::integral_constant<int, 1>{}, kq[1]);
+            sfor<4>([&](auto kbt) {
+                constexpr int kb = decltype(kbt)::value;
+                if constexpr (kb + 2 < 4) issue_k(std::integral_constant<int, (kb + 2) % 4>{}, kq[(kb + 2) % 3]);
                 if (kb < 2) lds_wait<KS, 2 * KS>(kq[kb % 3]);
                 else if (kb == 2) lds_wait<KS, KS>(kq[kb % 3]);
                 else lds_wait<KS, 0>(kq[kb % 3]);
@@ -431,23 +474,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
 #pragma unroll
                     for (int qs = 0; qs < 2; ++qs) s[qs][kb] = mfma16(kq[kb % 3][ks], qf[qs][ks], s[qs][kb]);
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            });
         }
         // V column fragments of the first two batches are fetched behind the softmax arithmetic
         TFrag vq[3][4];
         constexpr int NB = 2 * DB / 4;
-        auto issue_v = [&](int bi, TFrag (&dst)[4]) {
-            const int kp = bi / (DB / 4), db0 = (bi % (DB / 4)) * 4;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) rdcol_asm(dst[u], Vt, kp, db0 + u, lane);
+        auto issue_v = [&](auto bit, TFrag (&dst)[4]) {
+            constexpr int kp = decltype(bit)::value / (DB / 4), db0 = (decltype(bit)::value % (DB / 4)) * 4;
+            sfor<4>([&](auto u) { rdcol_imm<TILE + kp * 8192>(dst[decltype(u)::value], ad.col[db0 + decltype(u)::value]); });
         };
-        issue_v(0, vq[0]);
-        issue_v(1, vq[1]);
+        issue_v(std::integral_constant<int, 0>{}, vq[0]);
+        issue_v(std::integral_constant<int, 1>{}, vq[1]);
         // lane holds S^T[key = kv0 + 16kb + 4g + r][q = q0 + 16qs + c]
         const bool edge = !INTERIOR && ((kv0 + 64 > len) || (CAUSAL && kv0 + 63 > q0));     // wave-uniform
+        if (edge) {
 #pragma unroll
-        for (int qs = 0; qs < 2; ++qs) {
-            if (edge) {
+            for (int qs = 0; qs < 2; ++qs) {
                 const int qidx = q0 + qs * 16 + c;
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
@@ -458,12 +500,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
                         s[qs][kb][r] = ok ? s[qs][kb][r] : -INFINITY;
                     }
             }
-            float mx = fmaxf(fmaxf(s[qs][0][0], s[qs][0][1]), fmaxf(s[qs][0][2], s[qs][0][3]));
+        }
+        // row maxima: two v_max3 chains per 16-query block, the four chains interleaved (the asm statements keep their order)
+        float mxa[2], mxb[2];
 #pragma unroll
-            for (int kb = 1; kb < 4; ++kb) mx = fmaxf(mx, fmaxf(fmaxf(s[qs][kb][0], s[qs][kb][1]), fmaxf(s[qs][kb][2], s[qs][kb][3])));
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mnew = fmaxf(m[qs], mx * sl2);        // scale > 0: the maximum commutes with the scaling
+        for (int qs = 0; qs < 2; ++qs) { mxa[qs] = max3_asm(s[qs][0][0], s[qs][0][1], s[qs][0][2]); mxb[qs] = max3_asm(s[qs][0][3], s[qs][1][0], s[qs][1][1]); }
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) { mxa[qs] = max3_asm(mxa[qs], s[qs][1][2], s[qs][1][3]); mxb[qs] = max3_asm(mxb[qs], s[qs][2][0], s[qs][2][1]); }
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) { mxa[qs] = max3_asm(mxa[qs], s[qs][2][2], s[qs][2][3]); mxb[qs] = max3_asm(mxb[qs], s[qs][3][0], s[qs][3][1]); }
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) mxa[qs] = max3_asm(mxa[qs], s[qs][3][2], s[qs][3][3]);
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) mxa[qs] = max3_asm(mxa[qs], mxb[qs], mxb[qs]);
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            float mx = mxa[qs];
+            float sh = __shfl_xor(mx, 16, 64);
+            mx = max3_asm(mx, sh, sh);
+            sh = __shfl_xor(mx, 32, 64);
+            mx = max3_asm(mx, sh, sh);
+            const float ms = mx * sl2;                        // scale > 0: the maximum commutes with the scaling
+            const float mnew = max3_asm(m[qs], ms, ms);
             const float alpha = fexp2(m[qs] - mnew);
             float rs = 0.f;
 #pragma unroll
@@ -486,14 +544,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
             for (int kp = 0; kp < 2; ++kp)
 #pragma unroll
                 for (int qs = 0; qs < 2; ++qs) pf[kp][qs] = pack8(s[qs][2 * kp], s[qs][2 * kp + 1]);
-#pragma unroll
-            for (int bi = 0; bi < NB; ++bi) {
-                if (bi + 2 < NB) issue_v(bi + 2, vq[(bi + 2) % 3]);
+            sfor<NB>([&](auto bit) {
+                constexpr int bi = decltype(bit)::value;
+                if constexpr (bi + 2 < NB) issue_v(std::integral_constant<int, (bi + 2) % NB>{}, vq[(bi + 2) % 3]);
                 if (bi + 2 < NB) tf_wait4<15>(vq[bi % 3]);           // 16 younger reads in flight (the 4-bit counter saturates at 15)
                 else if (bi + 1 < NB) tf_wait4<8>(vq[bi % 3]);
                 else tf_wait4<0>(vq[bi % 3]);
                 __builtin_amdgcn_sched_barrier(0);
-                const int kp = bi / (DB / 4), db0 = (bi % (DB / 4)) * 4;
+                constexpr int kp = bi / (DB / 4), db0 = (bi % (DB / 4)) * 4;
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const bf16x8 vf = tf_get(vq[bi % 3][u]);
@@ -501,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
                     for (int qs = 0; qs < 2; ++qs) o[qs][db0 + u] = mfma16(vf, pf[kp][qs], o[qs][db0 + u]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            });
         }
     };
     // interior tiles: below the block's first query row (causal) and wholly inside the sample; never the last tile
@@ -583,6 +641,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_nat_kernel(AttnParams 
 
     plK.stage(rsK, hoff, smem, wid);
     plV.stage(rsV, hoff, smem + TILE, wid);
+    NatAddr ad;
+    ad.init(smem + STAGE, lane);          // the first tile's toggle brings it to stage 0
 
     // INTERIOR tiles (wholly below the block's first query row and inside the sample): no mask, no skipping wave, the next tile
     // always exists -- straight-line code; the tiles at the diagonal / the end of the sample take the general form.
@@ -590,8 +650,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_nat_kernel(AttnParams 
         constexpr bool INTERIOR = decltype(interior_tag)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const char* Kt = smem + (t & 1) * STAGE;
-        const char* Vt = Kt + TILE;
+        ad.shift((t & 1) ? STAGE : -STAGE);
         if (INTERIOR || t + 1 < ntiles) {
             char* nx = smem + ((t + 1) & 1) * STAGE;
             plK.stage(rsK, (t + 1) * kstep + hoff, nx, wid);
@@ -607,19 +666,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_nat_kernel(AttnParams 
             for (int kb = 0; kb < 4; ++kb) { s[qs][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qs][kb] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         {   // row fragments of K and V in batches of two k-steps: batch i + 1 is in flight while batch i's MFMAs run
             bf16x8 kq[2][2], vq[2][2];
-            auto issue = [&](int bi, bf16x8 (&kd)[2], bf16x8 (&vd)[2]) {
-                const int kb = bi >> 1, ks0 = (bi & 1) * 2;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) { rdrow_asm(kd[u], Kt, kb * 16 + c, (ks0 + u) * 4 + g); rdrow_asm(vd[u], Vt, kb * 16 + c, (ks0 + u) * 4 + g); }
+            auto issue = [&](auto bit, bf16x8 (&kd)[2], bf16x8 (&vd)[2]) {
+                constexpr int kb = decltype(bit)::value >> 1, ks0 = (decltype(bit)::value & 1) * 2;
+                sfor<2>([&](auto u) {
+                    rdrow_imm<kb * 4096>(kd[decltype(u)::value], ad.row[ks0 + decltype(u)::value]);
+                    rdrow_imm<TILE + kb * 4096>(vd[decltype(u)::value], ad.row[ks0 + decltype(u)::value]);
+                });
             };
-            issue(0, kq[0], vq[0]);
-#pragma unroll
-            for (int bi = 0; bi < 8; ++bi) {
-                if (bi + 1 < 8) issue(bi + 1, kq[(bi + 1) & 1], vq[(bi + 1) & 1]);
+            issue(std::integral_constant<int, 0>{}, kq[0], vq[0]);
+            sfor<8>([&](auto bit) {
+                constexpr int bi = decltype(bit)::value;
+                if constexpr (bi + 1 < 8) issue(std::integral_constant<int, (bi + 1) % 8>{}, kq[(bi + 1) & 1], vq[(bi + 1) & 1]);
                 if (bi + 1 < 8) { lds_wait<2, 4>(kq[bi & 1]); lds_wait<2, 4>(vq[bi & 1]); }
                 else { lds_wait<2, 0>(kq[bi & 1]); lds_wait<2, 0>(vq[bi & 1]); }
                 __builtin_amdgcn_sched_barrier(0);
-                const int kb = bi >> 1, ks0 = (bi & 1) * 2;
+                constexpr int kb = bi >> 1, ks0 = (bi & 1) * 2;
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -628,16 +689,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_nat_kernel(AttnParams 
                         dp[qs][kb] = mfma16(vq[bi & 1][u], dof[qs][ks0 + u], dp[qs][kb]);
                     }
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            });
         }
         // the K column fragments of the first dQ batch are fetched behind the elementwise part
         TFrag kc[4];
-        auto issue_c = [&](int bi) {
-            const int kp = bi / (DB / 4), db0 = (bi % (DB / 4)) * 4;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) rdcol_asm(kc[u], Kt, kp, db0 + u, lane);
+        auto issue_c = [&](auto bit) {
+            constexpr int kp = decltype(bit)::value / (DB / 4), db0 = (decltype(bit)::value % (DB / 4)) * 4;
+            sfor<4>([&](auto u) { rdcol_imm<kp * 8192>(kc[decltype(u)::value], ad.col[db0 + decltype(u)::value]); });
         };
-        issue_c(0);
+        issue_c(std::integral_constant<int, 0>{});
         const bool edge = !INTERIOR && ((kv0 + 64 > len) || (CAUSAL && kv0 + 63 > q0));
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
@@ -661,22 +721,22 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_nat_kernel(AttnParams 
         for (int kp = 0; kp < 2; ++kp)
 #pragma unroll
             for (int qs = 0; qs < 2; ++qs) dsf[kp][qs] = pack8(s[qs][2 * kp], s[qs][2 * kp + 1]);
-#pragma unroll
-        for (int bi = 0; bi < NB; ++bi) {
+        sfor<NB>([&](auto bit) {
+            constexpr int bi = decltype(bit)::value;
             tf_wait4<0>(kc);
             __builtin_amdgcn_sched_barrier(0);
             bf16x8 ktf[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) ktf[u] = tf_get(kc[u]);
             __builtin_amdgcn_sched_barrier(0);
-            if (bi + 1 < NB) issue_c(bi + 1);          // the next batch lands behind this batch's MFMAs
-            const int kp = bi / (DB / 4), db0 = (bi % (DB / 4)) * 4;
+            if constexpr (bi + 1 < NB) issue_c(std::integral_constant<int, (bi + 1) % NB>{});          // the next batch lands behind this batch's MFMAs
+            constexpr int kp = bi / (DB / 4), db0 = (bi % (DB / 4)) * 4;
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int qs = 0; qs < 2; ++qs) dq[qs][db0 + u] = mfma16(ktf[u], dsf[kp][qs], dq[qs][db0 + u]);
             __builtin_amdgcn_sched_barrier(0);
-        }
+        });
     };
     const int n_int = min(CAUSAL ? min(qblk * (NW / 2), len >> 6) : (len >> 6), ntiles - 1);
     int t = 0;
@@ -747,79 +807,96 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_nat_kernel(AttnParams
         }
     };
     if (n_it > 0) stage(0, smem);
+    NatAddr ad;
+    ad.init(smem + STAGE, lane);          // the first iteration's toggle brings it to stage 0
 
-    for (int it = 0; it < n_it; ++it) {
-        const int t = t0 + it % nt;
+    // One 64-query tile.  EDGE tiles (the diagonal, the end of the sample, a key block that crosses the end of the sample) evaluate
+    // the mask and may be skipped by a wave; all others run mask-free straight-line code (three sequential loops per query head
+    // below: two copies of the body under one branch made hipcc keep both register sets live -> scratch).
+    auto iter = [&](int it, int j, auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const char* Qt = smem + (it & 1) * STAGE;
-        const char* dOt = Qt + TILE;
-        const char* LSt = Qt + 2 * TILE;   // [64 lse | 64 delta] fp32
+        ad.shift((it & 1) ? STAGE : -STAGE);
+        const char* LSt = smem + (it & 1) * STAGE + 2 * TILE;   // [64 lse | 64 delta] fp32 behind the Q | dO images
         if (it + 1 < n_it) stage(it + 1, smem + ((it + 1) & 1) * STAGE);
-        const int qt0 = t * 64;
-        if (CAUSAL && qt0 + 63 < k0) continue;  // every query of this tile precedes this wave's keys
-        const bool edge = (qt0 + 64 > q_end) || (k0 + 16 > len) || (CAUSAL && qt0 < k0 + 15);
-
+        const int qt0 = (t0 + j) * 64;
+        if (EDGE && CAUSAL && qt0 + 63 < k0) return;  // every query of this tile precedes this wave's keys
+        {
+            sfor<2>([&](auto qpt) {
+                constexpr int qp = decltype(qpt)::value;
+                // column fragments of this 32-query step (for dV, dK) are fetched first: they are consumed last
+                TFrag dc[2][4], qc[2][4];
+                auto issue_c = [&](auto bit, TFrag (&dd)[4], TFrag (&qd)[4]) {
+                    constexpr int bi = decltype(bit)::value;
+                    sfor<4>([&](auto u) {
+                        rdcol_imm<TILE + qp * 8192>(dd[decltype(u)::value], ad.col[bi * 4 + decltype(u)::value]);
+                        rdcol_imm<qp * 8192>(qd[decltype(u)::value], ad.col[bi * 4 + decltype(u)::value]);
+                    });
+                };
+                f32x4 s[2], dp[2];
+                s[0] = s[1] = dp[0] = dp[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                bf16x8 qa[2][KS], da[2][KS];
+                sfor<2>([&](auto qq) {
+                    sfor<KS>([&](auto ks) {
+                        rdrow_imm<(2 * qp + decltype(qq)::value) * 4096>(qa[decltype(qq)::value][decltype(ks)::value], ad.row[decltype(ks)::value]);
+                        rdrow_imm<TILE + (2 * qp + decltype(qq)::value) * 4096>(da[decltype(qq)::value][decltype(ks)::value], ad.row[decltype(ks)::value]);
+                    });
+                });
+                lds_wait<KS, 2 * KS>(qa[0]); lds_wait<KS, 2 * KS>(da[0]);       // the 8 reads of the second 16-query block stay in flight
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int qp = 0; qp < 2; ++qp) {
-            // column fragments of this 32-query step (for dV, dK) are fetched first: they are consumed last
-            TFrag dc[2][4], qc[2][4];
-            auto issue_c = [&](int bi, TFrag (&dd)[4], TFrag (&qd)[4]) {
+                for (int ks = 0; ks < KS; ++ks) { s[0] = mfma16(qa[0][ks], kf[ks], s[0]); dp[0] = mfma16(da[0][ks], vf[ks], dp[0]); }
+                __builtin_amdgcn_sched_barrier(0);
+                issue_c(std::integral_constant<int, 0>{}, dc[0], qc[0]);        // 16 column reads, consumed after the elementwise part
+                lds_wait<KS, 15>(qa[1]); lds_wait<KS, 15>(da[1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { rdcol_asm(dd[u], dOt, qp, bi * 4 + u, lane); rdcol_asm(qd[u], Qt, qp, bi * 4 + u, lane); }
-            };
-            f32x4 s[2], dp[2];
-            s[0] = s[1] = dp[0] = dp[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            bf16x8 qa[2][KS], da[2][KS];
+                for (int ks = 0; ks < KS; ++ks) { s[1] = mfma16(qa[1][ks], kf[ks], s[1]); dp[1] = mfma16(da[1][ks], vf[ks], dp[1]); }
+                __builtin_amdgcn_sched_barrier(0);
+                // lane holds S[q = qt0 + 16qb + 4g + r][key = k0 + c]
 #pragma unroll
-            for (int qq = 0; qq < 2; ++qq)
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int qrow = qt0 + (2 * qp + qq) * 16 + 4 * g;
+                    const f32x4 ls = *(const f32x4*)(LSt + (qrow - qt0) * 4);
+                    const f32x4 dl = *(const f32x4*)(LSt + 256 + (qrow - qt0) * 4);
+                    const int kidx = k0 + c;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    rdrow_asm(qa[qq][ks], Qt, (2 * qp + qq) * 16 + c, ks * 4 + g);
-                    rdrow_asm(da[qq][ks], dOt, (2 * qp + qq) * 16 + c, ks * 4 + g);
-                }
-            lds_wait<KS, 2 * KS>(qa[0]); lds_wait<KS, 2 * KS>(da[0]);       // the 8 reads of the second 16-query block stay in flight
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) { s[0] = mfma16(qa[0][ks], kf[ks], s[0]); dp[0] = mfma16(da[0][ks], vf[ks], dp[0]); }
-            __builtin_amdgcn_sched_barrier(0);
-            issue_c(0, dc[0], qc[0]);                                        // 16 column reads, consumed after the elementwise part
-            lds_wait<KS, 15>(qa[1]); lds_wait<KS, 15>(da[1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) { s[1] = mfma16(qa[1][ks], kf[ks], s[1]); dp[1] = mfma16(da[1][ks], vf[ks], dp[1]); }
-            __builtin_amdgcn_sched_barrier(0);
-            // lane holds S[q = qt0 + 16qb + 4g + r][key = k0 + c]
-#pragma unroll
-            for (int qq = 0; qq < 2; ++qq) {
-                const int qrow = qt0 + (2 * qp + qq) * 16 + 4 * g;
-                const f32x4 ls = *(const f32x4*)(LSt + (qrow - qt0) * 4);
-                const f32x4 dl = *(const f32x4*)(LSt + 256 + (qrow - qt0) * 4);
-                const int kidx = k0 + c;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float p = fexp2(__builtin_fmaf(s[qq][r], sl2, -ls[r] * LOG2E));
-                    if (edge) {
-                        const int qidx = qrow + r;
-                        p = ((kidx < len) && (qidx < q_end) && (!CAUSAL || kidx <= qidx)) ? p : 0.f;
+                    for (int r = 0; r < 4; ++r) {
+                        float p = fexp2(__builtin_fmaf(s[qq][r], sl2, -ls[r] * LOG2E));
+                        if (EDGE) {
+                            const int qidx = qrow + r;
+                            p = ((kidx < len) && (qidx < q_end) && (!CAUSAL || kidx <= qidx)) ? p : 0.f;
+                        }
+                        s[qq][r] = p;
+                        dp[qq][r] = p * (dp[qq][r] - dl[r]);
                     }
-                    s[qq][r] = p;
-                    dp[qq][r] = p * (dp[qq][r] - dl[r]);
                 }
-            }
-            const bf16x8 pf = pack8(s[0], s[1]), dsf = pack8(dp[0], dp[1]);
+                const bf16x8 pf = pack8(s[0], s[1]), dsf = pack8(dp[0], dp[1]);
+                sfor<2>([&](auto bit) {
+                    constexpr int bi = decltype(bit)::value;
+                    if constexpr (bi == 0) { issue_c(std::integral_constant<int, 1>{}, dc[1], qc[1]); tf_wait4<15>(dc[0]); tf_wait4<15>(qc[0]); }
+                    else { tf_wait4<0>(dc[1]); tf_wait4<0>(qc[1]); }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int bi = 0; bi < 2; ++bi) {
-                if (bi == 0) { issue_c(1, dc[1], qc[1]); tf_wait4<15>(dc[0]); tf_wait4<15>(qc[0]); }
-                else { tf_wait4<0>(dc[1]); tf_wait4<0>(qc[1]); }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    dv[bi * 4 + u] = mfma16(tf_get(dc[bi][u]), pf, dv[bi * 4 + u]);
-                    dk[bi * 4 + u] = mfma16(tf_get(qc[bi][u]), dsf, dk[bi * 4 + u]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+                    for (int u = 0; u < 4; ++u) {
+                        dv[bi * 4 + u] = mfma16(tf_get(dc[bi][u]), pf, dv[bi * 4 + u]);
+                        dk[bi * 4 + u] = mfma16(tf_get(qc[bi][u]), dsf, dk[bi * 4 + u]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+        }
+    };
+    {
+        const bool key_partial = kblk * KPB + KPB > len;
+        const int ne0 = key_partial ? nt : (CAUSAL ? min(nt, (KPB + 63) / 64) : 0);          // leading edge tiles (the diagonal)
+        const int ni = max(ne0, min(nt, (q_end >> 6) - t0));                                   // [ne0, ni): interior; [ni, nt): trailing edge
+        int it = 0;
+        for (int rep = 0; rep < P.qrep; ++rep) {
+            for (int j = 0; j < ne0; ++j, ++it) iter(it, j, std::true_type{});
+            for (int j = ne0; j < ni; ++j, ++it) iter(it, j, std::false_type{});
+            for (int j = ni; j < nt; ++j, ++it) iter(it, j, std::true_type{});
         }
     }
     // lane holds dV^T[d = 16db + 4g + r][key = k0 + c]
