@@ -346,6 +346,22 @@ template <int LEFT> DEVINL void tf_wait4(TFrag (&f)[4]) {
                  : "i"(LEFT) : "memory");
 }
 
+// Block -> (x block, head, sample).  Workgroups go to the 8 XCDs round-robin in linear order, and every XCD has its own 4-MiB L2: the
+// remap hands each XCD a CONTIGUOUS range of (sample, head) pairs, so the blocks that re-read one head's K / V (Q / dO) tiles share an L2
+// (with the plain grid order every L2 streamed every head: 5 TB/s of L2 misses at S = 3056).  HEAVY_LAST_FIRST: under a causal mask the
+// work of a query block grows with its index -- the longest blocks of a head are started first, so the launch does not end on them.
+template <bool HEAVY_LAST_FIRST>
+DEVINL void block_coords(int& xb, int& h, int& b) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    const int pid = xcd_remap(lin, gx * gy * (int)gridDim.z);
+    const int hh = pid / gx;
+    xb = pid - hh * gx;
+    if (HEAVY_LAST_FIRST) xb = gx - 1 - xb;
+    h = hh % gy;
+    b = hh / gy;
+}
+
 // Compile-time loop (the index is a constant expression inside the body: immediates of the asm reads below).
 template <int N, class F>
 DEVINL void sfor(F&& f) {
@@ -397,7 +413,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
     constexpr int HD = 128, KS = 4, DB = 8, TILE = 64 * 256, STAGE = 2 * TILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wid = wave_id(), lane = lane_id(), g = lane >> 4, c = lane & 15;
-    const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int qblk, h, b;
+    block_coords<CAUSAL>(qblk, h, b);
     const long rb = P.cu ? (long)P.cu[b] : (long)b * P.S;
     const int S = P.cu ? P.cu[b + 1] - P.cu[b] : P.S, q0 = qblk * 128 + wid * 32;
     if (qblk * 128 >= S) return;
@@ -594,7 +611,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_nat_kernel(AttnParams 
     constexpr int HD = 128, KS = 4, DB = 8, TILE = 64 * 256, STAGE = 2 * TILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wid = wave_id(), lane = lane_id(), g = lane >> 4, c = lane & 15;
-    const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int qblk, h, b;
+    block_coords<CAUSAL>(qblk, h, b);
     const long rb = P.cu ? (long)P.cu[b] : (long)b * P.S;
     const int S = P.cu ? P.cu[b + 1] - P.cu[b] : P.S, q0 = qblk * (32 * NW) + wid * 32;
     if (qblk * (32 * NW) >= S) return;
@@ -764,7 +782,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_nat_kernel(AttnParams
     constexpr int HD = 128, KS = 4, DB = 8, TILE = 64 * 256, STAGE = 2 * TILE + 1024;   // Q | dO | lse, delta
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wid = wave_id(), lane = lane_id(), g = lane >> 4, c = lane & 15;
-    const int kblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    int kblk, h, b;
+    block_coords<false>(kblk, h, b);          // low key blocks (the longest under a causal mask) are already first
     constexpr int KPB = NW * 16;   // keys per block
     const long rb = P.cu ? (long)P.cu[b] : (long)b * P.S;
     const int S = P.cu ? P.cu[b + 1] - P.cu[b] : P.S, k0 = kblk * KPB + wid * 16;
