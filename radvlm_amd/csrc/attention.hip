@@ -303,21 +303,21 @@ DEVINL void stage_nat(const bf16* src, long row_stride, int valid_rows, const bf
 // Buffer-addressed staging of a natural tile: resource = this sample's rows of the operand (rows past its end read as zero in
 // hardware, also through the scalar offset), per-lane byte offsets computed once per block, scalar offset = first row of the tile
 // (+ the head's column offset): an M0 write and a `buffer_load_dwordx4 ... lds` per piece, no per-piece address arithmetic or selects.
+// A wave's piece i covers rows (i NW + wid) 4 + (lane >> 4): consecutive pieces lie 4 NW rows apart (a multiple of 8: same swizzle term), so
+// ONE per-lane offset serves all of them and the piece index goes into the scalar offset.
 template <int NROWS, int NW>
 struct NatPlan {
-    int v[NROWS * 16 / 64 / NW];
+    int v0, step;
     DEVINL void init(long row_stride, int wid, int lane) {
-#pragma unroll
-        for (int i = 0; i < NROWS * 16 / 64 / NW; ++i) {
-            const int c = (i * NW + wid) * 64 + lane;
-            const int r = c >> 4, pch = c & 15;
-            v[i] = (int)(((long)r * row_stride + (pch ^ nswz(r)) * 8) * 2);
-        }
+        const int c = wid * 64 + lane;
+        const int r = c >> 4, pch = c & 15;
+        v0 = (int)(((long)r * row_stride + (pch ^ nswz(r)) * 8) * 2);
+        step = (int)(4 * NW * row_stride * 2);
     }
     DEVINL void stage(__amdgpu_buffer_rsrc_t rsrc, int soff, char* lds, int wid) const {
 #pragma unroll
         for (int i = 0; i < NROWS * 16 / 64 / NW; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + (i * NW + wid) * 1024), 16, v[i], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds + (i * NW + wid) * 1024), 16, v0, soff + i * step, 0, 0);
     }
 };
 DEVINL __amdgpu_buffer_rsrc_t rows_rsrc(const bf16* base, long rows, long row_stride) {
