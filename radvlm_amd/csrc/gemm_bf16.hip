@@ -392,6 +392,14 @@ DEVINL void fissue(Frag& f, const char* tile, unsigned base_rowmajor, int rowbas
 }
 
 #define BAR_LGKM() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+// Wave priority around the MFMA clusters.  Round 1's per-phase s_setprio 1 / 0 flips paid while a staging piece cost four address
+// instructions; with the buffer-addressed, branch-free K loop they COST 3.3 % (same-box A/B over the decoder's shapes: NT +3-4 %, NN
+// +7-8 %, TT +0-1.6 % without them; a static s_setprio 1 for waves 4-7, RV_STATIC_PRIO, is +2.9 %) -- default: no priority games.
+#ifdef RV_PHASE_PRIO
+#define RV_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define RV_PRIO(x) do { } while (0)
+#endif
 #ifdef RV_STAMPS
 // diagnostic build: cycles wave 0 spends parked at the mid-tile barrier [0], the end-of-tile vmcnt wait [1] and barrier [2]
 #define RV_ACC_BEGIN() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg[3] = __builtin_readcyclecounter(); } while (0)
@@ -430,7 +438,7 @@ DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int br
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
         static_for<2>([&](auto j) { fissue<TB, true, 32 + decltype(j)::value * 16>(fb[1][decltype(j)::value][kk], Bt, bb[kk], brow0, kk, lane); });
-    __builtin_amdgcn_s_setprio(1);
+    RV_PRIO(1);
     // k-step 0 streams: each wait retires one more fragment (younger reads stay in flight) and releases the MFMAs it completes
     constexpr int R = G + B1_OPS;
 #define RV_C15(x) ((x) > 15 ? 15 : (x))
@@ -472,7 +480,7 @@ DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int br
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(b[0][j][1], a[i][1], acc[i][j]);
-    __builtin_amdgcn_s_setprio(0);
+    RV_PRIO(0);
 
     // ---- phase 2: B(nh1) has landed behind phase 1's MFMAs; A(mh1) is read k-step by k-step behind this phase's MFMAs
     ph2();
@@ -487,12 +495,12 @@ DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int br
         for (int j = 0; j < 2; ++j) b[1][j][kk] = frag_get<TB>(fb[1][j][kk]);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-        __builtin_amdgcn_s_setprio(1);
+        RV_PRIO(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma16(b[1][j][kk], a[i][kk], acc[i][2 + j]);
-        __builtin_amdgcn_s_setprio(0);
+        RV_PRIO(0);
         // a[.][kk] is dead now: fetch A(mh1) for this k-step while the other k-step's MFMAs run
         static_for<4>([&](auto i) { fissue<TA, false, 64 + decltype(i)::value * 16>(fa[decltype(i)::value][kk], At, ab[kk], 0, kk, lane); });
     }
@@ -506,24 +514,24 @@ DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int br
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i][kk] = frag_get<TA>(fa[i][kk]);
-        __builtin_amdgcn_s_setprio(1);
+        RV_PRIO(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = mfma16(b[1][j][kk], a[i][kk], acc[4 + i][2 + j]);
-        __builtin_amdgcn_s_setprio(0);
+        RV_PRIO(0);
     }
 
     // ---- phase 4
     ph4();
-    __builtin_amdgcn_s_setprio(1);
+    RV_PRIO(1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[4 + i][j] = mfma16(b[0][j][kk], a[i][kk], acc[4 + i][j]);
-    __builtin_amdgcn_s_setprio(0);
+    RV_PRIO(0);
 }
 
 template <int MODE>
@@ -796,6 +804,9 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
     __builtin_amdgcn_s_barrier();
     RV_STAMP(1);
 
+#ifdef RV_STATIC_PRIO
+    if (wid >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     int aslot = 0;          // A ring slot of tile t (t % 3)
     long long dbg[4] = {0, 0, 0, 0};   // diagnostic build only (RV_STAMPS): parked-cycle accumulators; dead code otherwise
     // One K-tile step.  STAGE = this step issues the staging of tile t + 2 (all steps but the last two): the steady-state loop is
