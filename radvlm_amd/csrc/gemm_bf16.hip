@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams P) {
 // of tile t-1 is free after the end barrier (reused by A(t+2)).  Every load is issued >= one K-tile (~2k cycles) before
 // its first use, stays in flight across both barriers (counted vmcnt + raw s_barrier, never vmcnt(0) in the loop).
 #ifndef RV_GROUP_M
-#define RV_GROUP_M 4      // tile rows per group of the block -> tile map (L2 locality; profiles/r02_gemm_tile_order_l2.json)
+#define RV_GROUP_M 4      // tile rows per group of the block -> tile map (L2 locality; profiles/r02_gemm_tile_order_l2.json; 8: -1.2 %, 16: -2.7 %)
 #endif
 constexpr int BM2 = 256, BN2 = 256;
 constexpr int HALF_BYTES = 128 * BK * 2;      // 16 KiB
@@ -424,7 +424,9 @@ DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int br
     // ---- phase 1: read A(mh0), B(nh0) and, ahead of time, B(nh1).  Every read is issued from asm and retired by counted
     // waits: the k-step-0 MFMAs start as soon as THEIR six fragments are back, the k-step-1 MFMAs after the next six, and
     // the B(nh1) prefetch stays in flight behind both (hipcc's own bookkeeping waited for all 16 reads before the first MFMA).
+#ifdef RV_PH1_EARLY
     ph1();
+#endif
     // issue order inside a k-step group: B0, A0, B1, A1, A2, A3 -- the first MFMA needs only the first two fragments
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -438,6 +440,9 @@ DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int br
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
         static_for<2>([&](auto j) { fissue<TB, true, 32 + decltype(j)::value * 16>(fb[1][decltype(j)::value][kk], Bt, bb[kk], brow0, kk, lane); });
+#ifndef RV_PH1_EARLY
+    ph1();   // this phase's two staging pieces go out behind its 16 fragment reads (not in front: +0.8 % over the decoder shapes)
+#endif
     RV_PRIO(1);
     // k-step 0 streams: each wait retires one more fragment (younger reads stay in flight) and releases the MFMAs it completes
     constexpr int R = G + B1_OPS;
@@ -483,10 +488,15 @@ DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int br
     RV_PRIO(0);
 
     // ---- phase 2: B(nh1) has landed behind phase 1's MFMAs; A(mh1) is read k-step by k-step behind this phase's MFMAs
+#ifndef RV_PH2_LATE
     ph2();
+#endif
     RV_ACC_BEGIN();
     BAR_LGKM();   // every wave's B reads of tile t are complete -> the B slot of tile t may be restaged
     RV_ACC_END(0);
+#ifdef RV_PH2_LATE
+    ph2();
+#endif
     fwait4<TB, 0>(fb[1][0][0], fb[1][1][0], fb[1][0][1], fb[1][1][1]);   // already retired by the barrier's wait: pins the consumers below it
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -506,11 +516,18 @@ DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int br
     }
 
     // ---- phase 3
+#ifndef RV_PH3_MID
     ph3();
+#endif
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         if (kk == 0) fwait4<TA, 4 * OA>(fa[0][0], fa[1][0], fa[2][0], fa[3][0]);   // the k-step-1 reads stay in flight
-        else fwait4<TA, 0>(fa[0][1], fa[1][1], fa[2][1], fa[3][1]);
+        else {
+#ifdef RV_PH3_MID
+            ph3();
+#endif
+            fwait4<TA, 0>(fa[0][1], fa[1][1], fa[2][1], fa[3][1]);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i][kk] = frag_get<TA>(fa[i][kk]);
@@ -523,14 +540,20 @@ DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int br
     }
 
     // ---- phase 4
+#ifndef RV_PH4_MID
     ph4();
+#endif
     RV_PRIO(1);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
+    for (int kk = 0; kk < 2; ++kk) {
+#ifdef RV_PH4_MID
+        if (kk == 1) { __builtin_amdgcn_sched_barrier(0); ph4(); __builtin_amdgcn_sched_barrier(0); }
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[4 + i][j] = mfma16(b[0][j][kk], a[i][kk], acc[4 + i][j]);
+    }
     RV_PRIO(0);
 }
 
