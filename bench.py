@@ -193,8 +193,8 @@ class GemmTimer:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=32, help="pairs per GPU per step (global batch 256 at 8 GPUs)")
     ap.add_argument("--geometry", default="llava15_7b")
     ap.add_argument("--no-cpu-baseline", action="store_true")
