@@ -849,6 +849,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_nat_kernel(AttnParams
         {
             sfor<2>([&](auto qpt) {
                 constexpr int qp = decltype(qpt)::value;
+                if (EDGE && CAUSAL && qt0 + qp * 32 + 31 < k0) return;   // diagonal tile: this 32-query step precedes all of the wave's keys
                 // column fragments of this 32-query step (for dV, dK) are fetched first: they are consumed last
                 TFrag dc[2][4], qc[2][4];
                 auto issue_c = [&](auto bit, TFrag (&dd)[4], TFrag (&qd)[4]) {
