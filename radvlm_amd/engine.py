@@ -240,6 +240,15 @@ class LlavaEngine:
             buf = self._stats[k] = torch.zeros(B, H, s_pad, dtype=torch.float32, device=self.device)
         return buf
 
+    def _dev(self, a):
+        """Host array -> device tensor through pinned memory, asynchronously.  A copy from pageable memory makes the runtime wait for the
+        stream first, i.e. the host could never enqueue ahead of the GPU (each of the ~10 index uploads of a step was such a wait: any host
+        hiccup then idled the GPU); torch's pinned-memory cache recycles a block only after the copy that used it has finished."""
+        t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+        if self.device.type != "cuda":
+            return t.to(self.device)
+        return t.pin_memory().to(self.device, non_blocking=True)
+
     def rope_table(self, S):
         if S not in self._rope:
             self._rope[S] = ops.rope_table(S, self.l["d"] // self.l["heads"], self.theta, self.device)
@@ -441,10 +450,10 @@ class LlavaEngine:
         table = torch.empty(n * self.P + n_extra + 1, d, dtype=BF16, device=self.device)
         ops.gemm_nt(a1, self.W("model.mm_projector.2.weight"), bias=self.W("model.mm_projector.2.bias"), out=table[:n * self.P])
         if rs:
-            t = lambda k: torch.from_numpy(rs[k]).to(self.device)
+            t = lambda k: self._dev(rs[k])
             ops.weighted_segment_sum_rows(table, t("fwd_off"), t("fwd_pos"), t("fwd_w"), t("fwd_out"), table)
         if mp:
-            which = ops.max4_rows_fwd(table, torch.from_numpy(mp["idx4"]).to(self.device), torch.from_numpy(mp["out"]).to(self.device), table)
+            which = ops.max4_rows_fwd(table, self._dev(mp["idx4"]), self._dev(mp["out"]), table)
             if save is not None:
                 save["pool_which"] = which
         if self.with_newline:
@@ -506,7 +515,7 @@ class LlavaEngine:
         plan = self.plan(input_ids, attention_mask, labels, images, image_sizes)
         self.lora_step += 1
         pix = torch.cat([(im if im.ndim == 4 else im[None]) for im in images], 0)
-        pix = pix.to(dev, non_blocking=True)
+        pix = (pix if pix.is_pinned() else pix.pin_memory()).to(dev, non_blocking=True)     # pinned: the copy does not stall the stream
         if pix.dtype == torch.uint8:
             # device-side normalisation: uint8 HWC tiles from the host (resize / crop / pad only), rescale + (x - mean) / std
             # + channel-first layout + bf16 cast here, in the processors' own fp32 arithmetic
@@ -540,14 +549,14 @@ class LlavaEngine:
                         tok_pos=remap(plan["tok_pos"]))
             ctx["plan"] = plan
             M = int(valid.sum())
-            cu = torch.from_numpy(np.concatenate([[0], np.cumsum(lens_np)]).astype(np.int32)).to(dev, non_blocking=True)
-            pos = torch.from_numpy((np.arange(B * S, dtype=np.int32) % S)[valid]).to(dev, non_blocking=True)
+            cu = self._dev(np.concatenate([[0], np.cumsum(lens_np)]).astype(np.int32))
+            pos = self._dev((np.arange(B * S, dtype=np.int32) % S)[valid])
             valid_idx = np.nonzero(valid)[0]
             lens = None
         else:
             M = B * S
-            lens = torch.from_numpy(lens_np).to(dev, non_blocking=True)
-        idx = torch.from_numpy(plan["idx"]).to(dev, non_blocking=True)
+            lens = self._dev(lens_np)
+        idx = self._dev(plan["idx"])
         x = ops.gather_rows(idx, d, self.W("model.embed_tokens.weight"), table)
         cs = self.rope_table(S)
         layers = []
@@ -599,7 +608,7 @@ class LlavaEngine:
         tgt = tgt.reshape(-1)
         if packed:
             tgt = tgt[valid_idx]
-        tgt_t = torch.from_numpy(tgt).to(dev, non_blocking=True)
+        tgt_t = self._dev(tgt)
         logits_out = None
         if want_logits:
             # callers get the reference's fp32 [B, S, V] (llava_llama.py:69-120 -> logits.float()): the lm_head GEMM once more with
@@ -607,7 +616,7 @@ class LlavaEngine:
             lf = ops.gemm_nt(hN, self.W("lm_head.weight"), out_dtype=torch.float32)
             if packed:          # padded shape, padding rows zero
                 logits_out = torch.zeros(B * S, V, dtype=torch.float32, device=dev)
-                logits_out[torch.from_numpy(valid_idx).to(dev)] = lf
+                logits_out[self._dev(valid_idx)] = lf
             else:
                 logits_out = lf
             logits_out = logits_out.view(B, S, V)[..., :self.vocab]
@@ -756,15 +765,15 @@ class LlavaEngine:
         dev = self.device
         # projector: rows of dx at the positions where projector outputs were spliced in (unused rows -> zero)
         n_rows = plan["n_feat_rows"]
-        fpos = torch.from_numpy(plan["feat_pos"]).to(dev)
+        fpos = self._dev(plan["feat_pos"])
         dfeat = ops.gather_rows(fpos, d, dx)
         rs = plan.get("resample")
         mp = plan.get("maxpool")
         if mp:   # adjoint of the 2x2 max pooling: each pooled row's gradient goes to the winning source element
-            ops.max4_rows_bwd(dfeat, torch.from_numpy(mp["idx4"]).to(dev), torch.from_numpy(mp["out"]).to(dev), c["pool_which"], dfeat)
+            ops.max4_rows_bwd(dfeat, self._dev(mp["idx4"]), self._dev(mp["out"]), c["pool_which"], dfeat)
             dfeat = dfeat[:plan["n_proj_rows"]]
         if rs:   # adjoint of the bilinear down-sampling: gradients of the created rows flow to their 4 source rows
-            t = lambda k: torch.from_numpy(rs[k]).to(dev)
+            t = lambda k: self._dev(rs[k])
             ops.weighted_segment_sum_rows(dfeat, t("adj_off"), t("adj_pos"), t("adj_w"), t("adj_out"), dfeat)
             dfeat = dfeat[:plan["n_proj_rows"]]
         g = self.G
@@ -781,8 +790,8 @@ class LlavaEngine:
             npos = plan["newline_pos"]
             if npos.size:
                 tmp = torch.zeros(1, d, dtype=BF16, device=dev)
-                ops.segment_sum_rows(dx, torch.tensor([0, npos.size], dtype=torch.int32, device=dev),
-                                     torch.from_numpy(npos).to(dev), torch.zeros(1, dtype=torch.int32, device=dev), tmp)
+                ops.segment_sum_rows(dx, self._dev(np.array([0, npos.size], dtype=np.int32)),
+                                     self._dev(npos), torch.zeros(1, dtype=torch.int32, device=dev), tmp)
                 gn.add_(tmp) if acc else gn.copy_(tmp)
         # embedding rows: segment sums by token id (no atomics)
         train_embed = "model.embed_tokens.weight" in self.lm.offsets     # full fine-tune, or the pretraining stage with extra tokens
@@ -791,13 +800,13 @@ class LlavaEngine:
             pass
         elif acc:
             tmp = torch.zeros_like(ge)
-            ops.segment_sum_rows(dx, torch.from_numpy(plan["tok_off"]).to(dev), torch.from_numpy(plan["tok_pos"]).to(dev),
-                                 torch.from_numpy(plan["tok_ids"]).to(dev), tmp)
+            ops.segment_sum_rows(dx, self._dev(plan["tok_off"]), self._dev(plan["tok_pos"]),
+                                 self._dev(plan["tok_ids"]), tmp)
             ge.add_(tmp)
         else:
             ge.zero_()
-            ops.segment_sum_rows(dx, torch.from_numpy(plan["tok_off"]).to(dev), torch.from_numpy(plan["tok_pos"]).to(dev),
-                                 torch.from_numpy(plan["tok_ids"]).to(dev), ge)
+            ops.segment_sum_rows(dx, self._dev(plan["tok_off"]), self._dev(plan["tok_pos"]),
+                                 self._dev(plan["tok_ids"]), ge)
         last = "model.image_newline" if self.with_newline else "model.mm_projector.2.bias"
         self._bucket_done("model.embed_tokens.weight" if train_embed else "model.mm_projector.0.weight", last)
         if self.train_tower:
