@@ -34,6 +34,7 @@ struct GemmParams {
     // MODE 3 (tail split): blocks [0, n_full) compute whole tiles; the remaining tiles of the last, partly filled round are
     // each split over `splits` K-slices (fp32 partial tiles in ws, combined by tail_reduce_kernel)
     int n_full;
+    int pgrid;     // persistent form: blocks [0, pgrid) walk the whole tiles with stride pgrid; MODE 3: blocks >= pgrid are the K-slices of the tail tiles
     // fused epilogues of the 256x256 kernel (EPI template parameter):
     //   EPI_ROPE        C = rope(A B^T + bias) on columns < rope_cols (q heads then k heads), table cs[pos][hd/2][cos,sin]
     //   EPI_SWIGLU_FWD  B = [gate; up] rows ([2F, K]); C = gate|up [M, 2F], C2 = silu(gate) * up [M, F]
@@ -760,28 +761,36 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
     RV_STAMP(0);
 
     const int nwg = P.tiles_m * P.tiles_n;
+    // PERSIST (plain whole-tile launches with buffer-addressed staging): a block walks the tiles blockIdx.x, + gridDim.x, ... (grid =
+    // min(tiles, CUs); same tile order per XCD as the one-tile-per-block launch) and issues the first K-tile of its NEXT output tile
+    // before the epilogue of the current one, so the fill of the staging pipeline and the launch gap hide behind the epilogue's stores.
+#ifdef RV_NO_PERSIST
+    constexpr bool PERSIST = false;
+#else
+    constexpr bool PERSIST = (MODE == 0 || MODE == 3) && BUF;
+#endif
     int vtile = blockIdx.x, kslice = 0;
     bool sliced = MODE == 2;
     if (MODE == 2) { vtile = (int)blockIdx.x / P.splits; kslice = (int)blockIdx.x % P.splits; }
-    if (MODE == 3 && (int)blockIdx.x >= P.n_full) {
-        const int r = (int)blockIdx.x - P.n_full;
+    if (MODE == 3 && (int)blockIdx.x >= (PERSIST ? P.pgrid : P.n_full)) {
+        const int r = (int)blockIdx.x - (PERSIST ? P.pgrid : P.n_full);
         vtile = P.n_full + r / P.splits; kslice = r % P.splits; sliced = true;
     }
-    int pid = xcd_remap(vtile, nwg);
-    constexpr int GROUP_M = RV_GROUP_M;
-    const int per_group = GROUP_M * P.tiles_n;
-    const int group = pid / per_group;
-    const int first_m = group * GROUP_M;
-    const int gsz = min(P.tiles_m - first_m, GROUP_M);
-    const int tm = first_m + (pid % per_group) % gsz;
-    const int tn = (pid % per_group) / gsz;
-    const int m0 = tm * BM2, n0 = tn * BN2;
+    int m0, n0, tn;
+    auto coords = [&](int vt) {
+        const int pid = xcd_remap(vt, nwg);
+        constexpr int GROUP_M = RV_GROUP_M;
+        const int per_group = GROUP_M * P.tiles_n;
+        const int group = pid / per_group;
+        const int first_m = group * GROUP_M;
+        const int gsz = min(P.tiles_m - first_m, GROUP_M);
+        tn = (pid % per_group) / gsz;
+        m0 = (first_m + (pid % per_group) % gsz) * BM2;
+        n0 = tn * BN2;
+    };
+    coords(vtile);
 
     f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // K-tile steps of this block: the whole K (MODE 0), K then K2 (MODE 1), or this block's slice of K (MODE 2)
     const int nt1 = (P.K + BK - 1) / BK;
@@ -793,6 +802,8 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
     if constexpr (BUF) {
         rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A, 0, P.bytesA, 0x00020000);
         rsB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B, 0, P.bytesB, 0x00020000);
+    }
+    auto make_plans = [&]() {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             plA[h] = plan_half<TA, false, 0>(P.lda, m0 + h * 128, P.M, wid, lane, h, 0, P.bytesA);
@@ -801,7 +812,8 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
             else if (EPI == EPI_SWIGLU_FWD) plB[h] = plan_half<TB, true, 2>(P.ldb, tn * 128, P.N, wid, lane, h, P.F, P.bytesB);
             else plB[h] = plan_half<TB, true, 0>(P.ldb, n0 + h * 128, P.N, wid, lane, h, 0, P.bytesB);
         }
-    }
+    };
+    if constexpr (BUF) make_plans();
     const int kstepA = TA ? (int)(P.lda * BK * 2) : BK * 2, kstepB = TB ? (int)(P.ldb * BK * 2) : BK * 2;    // bytes per K-tile
     auto stageA = [&](int t, int slot, int h) {
         char* dst = smem + (slot * 2 + h) * HALF_BYTES;
@@ -822,10 +834,16 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
 
     // prologue: tiles 0 and 1 (tile 1 stays in flight)
     stageA(0, 0, 0); stageA(0, 0, 1); stageB(0, 0); stageB(0, 1);
+    int vt0 = blockIdx.x;
+    do {    // one trip unless PERSIST
     if (nt > 1) { stageA(1, 1, 0); stageA(1, 1, 1); stageB(1, 0); stageB(1, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     RV_STAMP(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
 #ifdef RV_STATIC_PRIO
     if (wid >= 4) __builtin_amdgcn_s_setprio(1);
@@ -885,12 +903,22 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
             }
         return;
     }
-    if (EPI != EPI_NONE) epilogue_fused<EPI>(acc, P, m0, tn, wr, wc, lane);
-    else epilogue_256<MODE == 3 ? 0 : MODE>(acc, P, m0, n0, wr, wc, lane, kslice);
+    // (every wave's LDS reads of this tile are behind the last step's barrier: the rings are free)
+    const int m0e = m0, n0e = n0, tne = tn;
+    bool more = false;
+    if constexpr (PERSIST) {
+        vt0 += MODE == 3 ? P.pgrid : (int)gridDim.x;
+        more = !sliced && vt0 < (MODE == 3 ? P.n_full : nwg);
+        if (more) { coords(vt0); make_plans(); stageA(0, 0, 0); stageA(0, 0, 1); stageB(0, 0); stageB(0, 1); }
+    }
+    if (EPI != EPI_NONE) epilogue_fused<EPI>(acc, P, m0e, tne, wr, wc, lane);
+    else epilogue_256<MODE == 3 ? 0 : MODE>(acc, P, m0e, n0e, wr, wc, lane, kslice);
 #ifdef RV_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     RV_STAMP(3);
+    if (!more) break;
+    } while (PERSIST);
 }
 
 // C = act(alpha * sum_s ws[s] + bias) + residual  (finishes a split-K GEMM)
@@ -1000,7 +1028,15 @@ static void launch256m(const GemmParams& P, hipStream_t st) {
     if (!set) { (void)hipFuncSetAttribute((const void*)gemm_kernel_256<TA, TB, MODE, EPI_NONE, BUF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2); set = true; }
     const int nwg = P.tiles_m * P.tiles_n;
     const int blocks = MODE == 2 ? nwg * P.splits : (MODE == 3 ? P.n_full + (nwg - P.n_full) * P.splits : nwg);
-    hipLaunchKernelGGL((gemm_kernel_256<TA, TB, MODE, EPI_NONE, BUF>), dim3(blocks), dim3(512), LDS_BYTES2, st, P);
+    int grid = blocks;
+    GemmParams Q = P;
+    Q.pgrid = MODE == 3 ? P.n_full : blocks;
+#ifndef RV_NO_PERSIST
+    // persistent form: one block per CU walks the whole tiles (MODE 3: + the K-slice blocks of the tail tiles behind them)
+    if (BUF && MODE == 0 && blocks > cu_budget()) { grid = cu_budget(); Q.pgrid = grid; }
+    if (BUF && MODE == 3 && P.n_full > cu_budget()) { Q.pgrid = cu_budget(); grid = Q.pgrid + (nwg - P.n_full) * P.splits; }
+#endif
+    hipLaunchKernelGGL((gemm_kernel_256<TA, TB, MODE, EPI_NONE, BUF>), dim3(grid), dim3(512), LDS_BYTES2, st, Q);
     if (MODE == 3) hipLaunchKernelGGL(tail_reduce_kernel, dim3((nwg - P.n_full) * 32), dim3(256), 0, st, P);
     if (MODE == 2) {
         const long total = (long)P.M * P.N;
@@ -1107,7 +1143,11 @@ template <int EPI, bool TB, bool BUF>
 static void launch_fused1(const GemmParams& P, hipStream_t st) {
     static bool attr = false;      // once per instantiation (see the launch-configuration note above)
     if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_kernel_256<false, TB, 0, EPI, BUF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2); attr = true; }
-    hipLaunchKernelGGL((gemm_kernel_256<false, TB, 0, EPI, BUF>), dim3(P.tiles_m * P.tiles_n), dim3(512), LDS_BYTES2, st, P);
+    int grid = P.tiles_m * P.tiles_n;
+#ifndef RV_NO_PERSIST
+    if (BUF && grid > cu_budget()) grid = cu_budget();
+#endif
+    hipLaunchKernelGGL((gemm_kernel_256<false, TB, 0, EPI, BUF>), dim3(grid), dim3(512), LDS_BYTES2, st, P);
 }
 template <int EPI, bool TB>
 static int launch_fused(GemmParams& P, int tiles_m, int tiles_n, hipStream_t st) {
