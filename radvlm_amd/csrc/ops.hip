@@ -762,12 +762,11 @@ __global__ __launch_bounds__(TPB) void clip_coef_kernel(const float* partial, in
 }
 
 __global__ void cast_f32_bf16_kernel(const float* in, bf16* out, long n) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = f2bf(in[i]);
+    // grid-stride: a dispatch carries a 32-bit work-item count, and the flat parameter buffers of a 7B model have 6.8e9 elements
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = f2bf(in[i]);
 }
 __global__ void cast_bf16_f32_kernel(const bf16* in, float* out, long n) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = bf2f(in[i]);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = bf2f(in[i]);
 }
 __global__ void add_bf16_kernel(const bf16* a, const bf16* b, bf16* y, long n) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
@@ -782,7 +781,12 @@ __global__ void add_bf16_kernel(const bf16* a, const bf16* b, bf16* y, long n) {
     }
 }
 
-inline unsigned nblocks(long n, int per) { return (unsigned)((n + per - 1) / per); }
+inline unsigned nblocks(long n, int per) { const long b = (n + per - 1) / per; return b >= (1L << 24) ? 0u : (unsigned)b; }   // 0 blocks = a launch error, loudly (see below)
+// A dispatch's work-item count is a 32-bit field: blocks x threads must stay below 2^32 (a 7B model's flat buffers have 6.8e9 elements; a
+// launch over one work-item per element silently covered n mod 2^32 of them).  Grid-stride kernels cap their grid with this; the
+// others refuse such an n.
+inline unsigned nblocks_capped(long n, int per) { const long b = (n + per - 1) / per; return (unsigned)(b > (1L << 22) ? (1L << 22) : b); }
+inline bool fits_one_dispatch(long work_items) { return work_items < (1L << 32); }
 
 }  // namespace
 
@@ -986,7 +990,13 @@ extern "C" int rv_adamw(void* p, float* master, const void* g, float* m, float* 
     if (!p || !master || !g || !m || !v || n <= 0) return RV_ERR_ARG;
     if ((((uintptr_t)p) | ((uintptr_t)g)) & 7) return RV_ERR_ARG;
     if ((((uintptr_t)master) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return RV_ERR_ARG;
-    hipLaunchKernelGGL(adamw_kernel, dim3(nblocks((n + 3) / 4, 256)), dim3(256), 0, ST, (bf16*)p, master, (const bf16*)g, m, v, (long)n, lr, b1, b2, eps, wd, bc1, bc2, gscale);
+    // four elements per work-item; slices beyond 2^32 work-items (1.7e10 elements) go out as several dispatches
+    const int64_t chunk = (int64_t)1 << 33;
+    for (int64_t o = 0; o < n; o += chunk) {
+        const int64_t c = n - o < chunk ? n - o : chunk;
+        hipLaunchKernelGGL(adamw_kernel, dim3(nblocks((c + 3) / 4, 256)), dim3(256), 0, ST, (bf16*)p + o, master + o, (const bf16*)g + o, m + o, v + o, (long)c,
+                           lr, b1, b2, eps, wd, bc1, bc2, gscale);
+    }
     return rv_check_launch();
 }
 extern "C" int rv_sumsq_partial_bf16(const void* g, int64_t n, float* partial, int nblk, void* stream) {
@@ -1001,16 +1011,16 @@ extern "C" int rv_clip_coef(const float* partial, int nblk, float max_norm, floa
 }
 extern "C" int rv_cast_f32_to_bf16(const float* in, void* out, int64_t n, void* stream) {
     if (!in || !out || n <= 0) return RV_ERR_ARG;
-    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(nblocks(n, 256)), dim3(256), 0, ST, in, (bf16*)out, (long)n);
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(nblocks_capped(n, 256)), dim3(256), 0, ST, in, (bf16*)out, (long)n);
     return rv_check_launch();
 }
 extern "C" int rv_cast_bf16_to_f32(const void* in, float* out, int64_t n, void* stream) {
     if (!in || !out || n <= 0) return RV_ERR_ARG;
-    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(nblocks(n, 256)), dim3(256), 0, ST, (const bf16*)in, out, (long)n);
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(nblocks_capped(n, 256)), dim3(256), 0, ST, (const bf16*)in, out, (long)n);
     return rv_check_launch();
 }
 extern "C" int rv_add_bf16(const void* a, const void* b, void* y, int64_t n, void* stream) {
-    if (!a || !b || !y || n <= 0) return RV_ERR_ARG;
+    if (!a || !b || !y || n <= 0 || !fits_one_dispatch((n + 7) / 8)) return RV_ERR_ARG;
     hipLaunchKernelGGL(add_bf16_kernel, dim3(nblocks((n + 7) / 8, 256)), dim3(256), 0, ST, (const bf16*)a, (const bf16*)b, (bf16*)y, (long)n);
     return rv_check_launch();
 }

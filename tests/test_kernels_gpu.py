@@ -697,3 +697,33 @@ def test_device_side_image_normalisation_is_bit_identical_to_the_host_processor(
     proc.device_normalize = True
     u8 = proc.preprocess(Image.fromarray(canvases[1, :tile, :tile]))["pixel_values"][0]
     assert u8.dtype == torch.uint8 and np.array_equal(u8.numpy(), canvases[1, :tile, :tile])
+
+
+def test_flat_buffer_kernels_beyond_2_32_elements(ops):
+    """A dispatch's work-item count is a 32-bit field.  The flat parameter buffers of the 7B model have 6.8e9 elements: the bf16 -> fp32
+    cast that fills the AdamW master copy once launched one work-item per element and covered only n mod 2^32 of them (everything behind
+    -- the decoder layers from the 12th on, the final norm, lm_head -- became zero with the first optimizer step).  Cast both ways and run
+    one AdamW step over 2^32 + 4096 elements; the tail must be processed."""
+    n = (1 << 32) + 4096
+    x = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    x[-4096:] = 1.5
+    x[:4096] = -2.0
+    f = ops.to_f32(x)
+    assert float(f[-1]) == 1.5 and float(f[-4096]) == 1.5 and float(f[0]) == -2.0 and float(f[n // 2]) == 0.0
+    assert float(f[-4096:].sum()) == 1.5 * 4096
+    del x
+    f[-4096:] = 3.0
+    b = ops.to_bf16(f)
+    assert float(b[-1]) == 3.0 and float(b[0]) == -2.0 and float(b[-4096:].float().sum()) == 3.0 * 4096
+    del b
+    # AdamW, lr = 0.5 on a gradient of ones: first step moves every element by -0.5 (bias-corrected m / sqrt(v) = 1)
+    from radvlm_amd import lib
+    p = torch.zeros(n, dtype=torch.bfloat16, device="cuda")
+    g = torch.ones(n, dtype=torch.bfloat16, device="cuda")
+    m = torch.zeros(n, dtype=torch.float32, device="cuda")
+    v = torch.zeros(n, dtype=torch.float32, device="cuda")
+    f.zero_()
+    lib.call("rv_adamw", p, f, g, m, v, n, 0.5, 0.9, 0.999, 1e-8, 0.0, 1 - 0.9, 1 - 0.999, None)
+    torch.cuda.synchronize()
+    for i in (0, n // 2, n - 1):
+        assert abs(float(p[i]) + 0.5) < 1e-3 and abs(float(f[i]) + 0.5) < 1e-3, i
