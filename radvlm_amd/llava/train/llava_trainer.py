@@ -336,7 +336,7 @@ class LLaVATrainer:
                                    mm_vision_tower_lr=None if vlr is None else vlr * scale)
                 self.state["global_step"] = step
                 if step % max(1, getattr(a, "logging_steps", 1)) == 0:
-                    rec = {"step": step, "loss": float(sum(float(l) for l in losses) / len(losses)), "learning_rate": lr,
+                    rec = {"step": step, "loss": float(sum(float(l.detach()) for l in losses) / len(losses)), "learning_rate": lr,
                            "grad_norm": float(eng.last_grad_norm) if eng.last_grad_norm is not None else None,
                            "epoch": step / steps_per_epoch, "step_time_s": time.perf_counter() - t0, "data_wait_s": t_data}
                     self.state["log_history"].append(rec)
@@ -379,7 +379,7 @@ class LLaVATrainer:
             if not eng.lora:
                 proj = {k: v.detach().clone().cpu() for k, v in eng.state_dict().items() if "mm_projector" in k}
                 torch.save(proj, os.path.join(path, "mm_projector.bin"))
-        if eng.master is not None:
+        if eng.master is not None and not getattr(self.args, "save_only_model", False):
             save_file({"master": eng.master.detach().cpu(), "exp_avg": eng.m.detach().cpu(), "exp_avg_sq": eng.vv.detach().cpu()},
                       os.path.join(path, "optimizer.safetensors"))
         with open(os.path.join(path, "trainer_state.json"), "w") as f:
@@ -412,7 +412,7 @@ class LLaVATrainer:
             eng.master.copy_(st["master"]), eng.m.copy_(st["exp_avg"]), eng.vv.copy_(st["exp_avg_sq"])
         with open(os.path.join(path, "trainer_state.json")) as f:
             ts = json.load(f)
-        eng.opt_step = ts["opt_step"]
+        eng.opt_step = ts["opt_step"] if os.path.exists(opt) else 0      # save_only_model checkpoints: a fresh optimizer, as HF restarts it
         eng.lora_step = ts.get("lora_step", eng.lora_step)      # the dropout masks of a resumed LoRA run continue their counter
         self.state["global_step"] = ts["global_step"]
         self.state["log_history"] = ts["log_history"]

@@ -133,6 +133,7 @@ class TrainingArguments:
     save_strategy: str = "steps"
     save_steps: int = 500
     save_total_limit: Optional[int] = None
+    save_only_model: bool = False        # HF TrainingArguments.save_only_model: checkpoints without optimizer state (a 7B AdamW state is 81 GB)
     evaluation_strategy: str = "no"
     dataloader_num_workers: int = 4
     dataloader_drop_last: bool = False

@@ -25,7 +25,7 @@ tok = Tok(); tok.model_max_length = 2048
 common = ["--data_path", os.path.join(tmp, "d.json"), "--image_folder", tmp, "--image_aspect_ratio", "pad", "--version", "v1", "--geometry", "llava15_7b",
           "--per_device_train_batch_size", "8", "--gradient_accumulation_steps", "2", "--learning_rate", "2e-5", "--warmup_ratio", "0.03",
           "--mm_projector_type", "mlp2x_gelu", "--mm_vision_select_layer", "-2", "--mm_use_im_patch_token", "False", "--model_max_length", "2048",
-          "--dataloader_num_workers", "4", "--logging_steps", "1", "--save_steps", "2", "--output_dir", os.path.join(tmp, "out")]
+          "--dataloader_num_workers", "4", "--logging_steps", "1", "--save_steps", "2", "--save_only_model", "True", "--output_dir", os.path.join(tmp, "out")]
 t = time.time()
 st = train(argv=common + ["--max_steps", "3"], tokenizer=tok)
 print("run 1:", {k: st[k] for k in st if k in ("global_step", "log")} if isinstance(st, dict) else st, f"{time.time() - t:.0f} s", flush=True)
