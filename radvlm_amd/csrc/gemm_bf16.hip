@@ -719,14 +719,8 @@ DEVINL void epilogue_fused(const f32x4 (&acc)[8][4], const GemmParams& P, int m0
     });
     if (EPI == EPI_SWIGLU_BWD) {
         // acc = d(act) of columns n .. n+7 (natural column order); d gate = da * up * silu'(gate), d up = da * silu(gate)
-        static_for<16>([&](auto ia) {
-            constexpr int i = decltype(ia)::value >> 1, a = decltype(ia)::value & 1;
-            const int m = m0 + wr * 128 + i * 16 + (lane & 15);
-            const int n = tn * BN2 + wc * 64 + 32 * a + 8 * q;
-            if (m >= P.M || n >= P.F) return;
-            const f32x4 x0 = acc[i][2 * a], x1 = acc[i][2 * a + 1];
+        auto dswiglu = [&](const f32x4& x0, const f32x4& x1, const bf16x8& gv, const bf16x8& uv, bf16* cp_g, bf16* cp_u) {
             const float da[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
-            const bf16x8 gv = *(const bf16x8*)(P.G + (long)m * P.ldg + n), uv = *(const bf16x8*)(P.G + (long)m * P.ldg + P.F + n);
             float dg[8], du[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -735,9 +729,44 @@ DEVINL void epilogue_fused(const f32x4 (&acc)[8][4], const GemmParams& P, int m0
                 du[r] = d * (g * sg);
                 dg[r] = d * u * (sg * (1.f + g * (1.f - sg)));
             }
+            store8(cp_g, dg);
+            store8(cp_u, du);
+        };
+        if (m0 + BM2 <= P.M && tn * BN2 + BN2 <= P.F) {
+            // interior tile: the 32 gate / up vectors of a lane are fetched in four batches of eight, the next batch in flight behind the
+            // arithmetic of the current one (one load -> use round trip per 16-row block made this epilogue latency-bound: ~25 us per tile)
+            const bf16* gp = P.G + (long)(m0 + wr * 128 + (lane & 15)) * P.ldg + tn * BN2 + wc * 64 + 8 * q;
+            bf16* cp = (bf16*)P.C + (long)(m0 + wr * 128 + (lane & 15)) * P.ldc + tn * BN2 + wc * 64 + 8 * q;
+            bf16x8 gq[2][4], uq[2][4];
+            auto fetch = [&](int bi, bf16x8 (&gd)[4], bf16x8 (&ud)[4]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ia = bi * 4 + u, i = ia >> 1, a = ia & 1;
+                    const bf16* p = gp + (long)i * 16 * P.ldg + 32 * a;
+                    gd[u] = *(const bf16x8*)p;
+                    ud[u] = *(const bf16x8*)(p + P.F);
+                }
+            };
+            fetch(0, gq[0], uq[0]);
+            static_for<4>([&](auto bt) {
+                constexpr int bi = decltype(bt)::value;
+                if constexpr (bi + 1 < 4) fetch(bi + 1, gq[(bi + 1) & 1], uq[(bi + 1) & 1]);
+                static_for<4>([&](auto ut) {
+                    constexpr int u = decltype(ut)::value, ia = bi * 4 + u, i = ia >> 1, a = ia & 1;
+                    bf16* c = cp + (long)i * 16 * P.ldc + 32 * a;
+                    dswiglu(acc[i][2 * a], acc[i][2 * a + 1], gq[bi & 1][u], uq[bi & 1][u], c, c + P.F);
+                });
+            });
+            return;
+        }
+        static_for<16>([&](auto ia) {
+            constexpr int i = decltype(ia)::value >> 1, a = decltype(ia)::value & 1;
+            const int m = m0 + wr * 128 + i * 16 + (lane & 15);
+            const int n = tn * BN2 + wc * 64 + 32 * a + 8 * q;
+            if (m >= P.M || n >= P.F) return;
+            const bf16x8 gv = *(const bf16x8*)(P.G + (long)m * P.ldg + n), uv = *(const bf16x8*)(P.G + (long)m * P.ldg + P.F + n);
             bf16* cp = (bf16*)P.C + (long)m * P.ldc;
-            store8(cp + n, dg);
-            store8(cp + P.F + n, du);
+            dswiglu(acc[i][2 * a], acc[i][2 * a + 1], gv, uv, cp + n, cp + P.F + n);
         });
     }
 }
