@@ -725,7 +725,7 @@ DEVINL void epilogue_fused(const f32x4 (&acc)[8][4], const GemmParams& P, int m0
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const float g = bf2f(gv[r]), u = bf2f(uv[r]), d = rbf16(da[r]);   // d(act) was a bf16 tensor in the unfused path
-                const float sg = 1.f / (1.f + __expf(-g));
+                const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-g));   // v_rcp_f32 (1 ulp), as swiglu_bwd_kernel: an IEEE division is 10 instructions, 128 per lane here
                 du[r] = d * (g * sg);
                 dg[r] = d * u * (sg * (1.f + g * (1.f - sg)));
             }

@@ -335,7 +335,7 @@ __global__ void swiglu_bwd_kernel(const bf16* dact, long ld_dact, const bf16* gu
     ld8(dact + r * ld_dact + f, da);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const float sg = 1.f / (1.f + __expf(-g[i]));
+        const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-g[i]));   // the same expression as the fused dgrad epilogue (gemm_bf16.hip): bit-identical results
         const float silu = g[i] * sg;
         du[i] = da[i] * silu;
         dg[i] = da[i] * u[i] * (sg * (1.f + g[i] * (1.f - sg)));
