@@ -1292,8 +1292,11 @@ extern "C" int rv_attn_fwd_gqa(const void* q, int64_t ld_q, const void* k, int64
 namespace {
 template __global__ void attn_fwd_nat_kernel<true>(AttnParams);
 template __global__ void attn_fwd_nat_kernel<false>(AttnParams);
-template __global__ void attn_bwd_dq_nat_kernel<true, 8>(AttnParams);
-template __global__ void attn_bwd_dq_nat_kernel<false, 8>(AttnParams);
+#ifndef RV_DQ_NW
+#define RV_DQ_NW 4
+#endif
+template __global__ void attn_bwd_dq_nat_kernel<true, RV_DQ_NW>(AttnParams);
+template __global__ void attn_bwd_dq_nat_kernel<false, RV_DQ_NW>(AttnParams);
 template __global__ void attn_bwd_dkv_nat_kernel<true, 4>(AttnParams);
 template __global__ void attn_bwd_dkv_nat_kernel<false, 4>(AttnParams);
 }  // namespace
@@ -1400,7 +1403,7 @@ extern "C" int rv_attn_bwd_nat(const void* q, int64_t ld_q, const void* k, int64
     P.B = B; P.H = H; P.S = S; P.S_pad = S_pad; P.scale = scale; P.Hkv = H_kv; P.nrep = H / H_kv;
     P.rope_cs = rope_cos_sin; P.rope_pos = rope_positions; P.rope_dk = 1;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid_dq((S + 255) / 256, H, B), grid_dkv((S + 63) / 64, H_kv, B);
+    dim3 grid_dq((S + 32 * RV_DQ_NW - 1) / (32 * RV_DQ_NW), H, B), grid_dkv((S + 63) / 64, H_kv, B);
     AttnParams PK = P;
     PK.kdiv = 1; PK.qrep = P.nrep;
     const long rows_all = cu_rows ? (long)total_rows : (long)B * S;
@@ -1419,9 +1422,9 @@ extern "C" int rv_attn_bwd_nat(const void* q, int64_t ld_q, const void* k, int64
     // against 8-wave blocks of 128 keys: -10 % at S = 704, -3 % at S = 3056, -1 % at S = 7499)
 #define LAUNCH_BWD_NAT(C_)                                                                                 \
     do {                                                                                                   \
-        set_smem(attn_bwd_dq_nat_kernel<C_, 8>, smem_dq);                                                  \
+        set_smem(attn_bwd_dq_nat_kernel<C_, RV_DQ_NW>, smem_dq);                                                  \
         set_smem(attn_bwd_dkv_nat_kernel<C_, 4>, smem_dkv);                                                \
-        hipLaunchKernelGGL((attn_bwd_dq_nat_kernel<C_, 8>), grid_dq, dim3(512), smem_dq, st, P);           \
+        hipLaunchKernelGGL((attn_bwd_dq_nat_kernel<C_, RV_DQ_NW>), grid_dq, dim3(64 * RV_DQ_NW), smem_dq, st, P);           \
         hipLaunchKernelGGL((attn_bwd_dkv_nat_kernel<C_, 4>), grid_dkv, dim3(256), smem_dkv, st, PK);       \
     } while (0)
     if (causal) LAUNCH_BWD_NAT(true); else LAUNCH_BWD_NAT(false);
