@@ -356,6 +356,9 @@ def main():
     if tf_pair:
         roofline["step_algorithmic_tflops"] = tf_pair * args.batch / (ms_per_step * 1e-3)
         roofline["step_frac_of_mfma_peak"] = roofline["step_algorithmic_tflops"] / PEAK_BF16_TFLOPS
+    # sequence length of the spliced decoder input for the fixed-shape cxr workload: image tokens + ids - the placeholder
+    v = geo["vision"]
+    s_cxr = (v["image"] // v["patch"]) ** 2 + 129 - 1
     if rank == 0:
         out = {
             "metric": ("train image-instruction pairs/sec, LLaVA-OV Qwen2-7B + SigLIP-so400m 384px anyres_max_9 (SURVEY 8f.1; not the "
@@ -367,9 +370,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.geometry} {'LoRA r=64' if args.workload == 'lora' else 'full fine-tune'} step "
                                    f"({'tower tunable' if args.workload == 'radvlm' else 'ViT frozen'}): fwd+bwd+AdamW, "
-                                   f"{ {'anyres': 'anyres 5 tiles, S=3056', 'radvlm': 'anyres_max_9 10 tiles, S=7499'}.get(args.workload, 'S=704')}, "
+                                   f"{ {'anyres': 'anyres 5 tiles, S=3056', 'radvlm': 'anyres_max_9 10 tiles, S=7499'}.get(args.workload, 'S=%d' % s_cxr)}, "
                                    f"{args.batch} pairs/GPU/step", "global_batch": args.batch * world,
-                       "seq_len": {"anyres": 3056, "radvlm": 7499}.get(args.workload, 704),
+                       "seq_len": {"anyres": 3056, "radvlm": 7499}.get(args.workload, s_cxr),
                        "parallelism": f"dp{world}", "final_loss": final_loss,
                        **({"text_lens": args.text_lens, "packed": args.packed} if args.text_lens else {})},
             "roofline": roofline,
