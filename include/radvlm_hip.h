@@ -82,8 +82,10 @@ int rv_gemm_swiglu_fwd_bf16(const void* A, int64_t lda, const void* Wgu, int64_t
 int rv_gemm_swiglu_bwd_bf16(const void* dY, int64_t ldy, const void* Wd, int64_t ldw, const void* GU, int64_t ldgu, void* dGU, int64_t lddgu,
                             void* dact_scratch, int64_t ld_dact, int M, int F, int K, void* workspace, int64_t workspace_bytes,
                             const void* zeros16, void* stream);
-/* Measurement hook (A/B tools and tests only; the product path never calls it): 0 = automatic tile selection (default),
- * 1 = 128x128 tile kernel, 2 = 256x256 tile kernel, 20 / 21 = tail split off / on.  Process-wide. */
+/* Launch-shape selection, process-wide.  Measurement hooks (A/B tools and tests only): 0 = automatic tile selection (default),
+ * 1 = 128x128 tile kernel, 2 = 256x256 tile kernel, 20 / 21 = tail split off / on, 30 / 31 = buffer-addressed staging off / on.
+ * 40 / 41 = persistent tile-walking blocks off / on (default on): the engine turns them OFF for world size > 1, where RCCL kernels
+ * share the CUs -- a persistent block that cannot start delays its whole share of the tiles.  Results never depend on any of it. */
 int rv_gemm_select_kernel(int which);
 /* Compute units the GEMM plans its tile rounds for (whole rounds of one 256x256 tile per CU, the K-split of a half-empty last
  * round, split-K of small outputs).  total_cus <= 0: the current device's multiProcessorCount (256 on MI355X); reserved_cus:

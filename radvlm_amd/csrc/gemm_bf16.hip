@@ -1003,6 +1003,7 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(GemmParams P) {
 
 // ---- process-wide launch configuration (the ONLY state this file keeps; one process drives one GPU) ----------
 //   g_tail_split / g_force_kernel : measurement hooks (rv_gemm_select_kernel; RV_GEMM_KERNEL at first use)
+//   g_persist                     : persistent blocks on (single GPU) / off (collectives share the CUs), rv_gemm_select_kernel(41 / 40)
 //   g_cus                         : compute units the tile-round heuristics plan for = the device's multiProcessorCount minus the
 //                                   units reserved for concurrently running collectives (rv_gemm_set_cu_budget / RV_GEMM_RESERVED_CUS);
 //                                   queried once per process on first use
@@ -1013,7 +1014,11 @@ static int g_force_kernel = 0;  // 0 auto, 1 = 128x128 kernel, 2 = 256x256 kerne
 static int g_cus = 0;           // 0 = not yet queried
 static int g_reserved_cus = -1; // -1 = take RV_GEMM_RESERVED_CUS (default 0) at first use
 static int g_no_buf = 0;         // rv_gemm_select_kernel(30 / 31): buffer-addressed staging off / on (A/B measurement)
+static int g_persist = 1;        // rv_gemm_select_kernel(40 / 41): persistent tile-walking blocks off / on.  OFF when collectives share the GPU
+                                 // (the engine does that for world size > 1): a persistent block that cannot start because an RCCL kernel holds
+                                 // its CU delays its whole share of the tiles (up to 2x for the launch); one-tile blocks only lose part of a round
 extern "C" int rv_gemm_select_kernel(int which) {
+    if (which >= 40) { g_persist = which == 41; return RV_OK; }
     if (which >= 30) { g_no_buf = which == 30; return RV_OK; }
     if (which >= 20) { g_tail_split = which - 20; return RV_OK; }
     g_force_kernel = which;
@@ -1062,8 +1067,8 @@ static void launch256m(const GemmParams& P, hipStream_t st) {
     Q.pgrid = MODE == 3 ? P.n_full : blocks;
 #ifndef RV_NO_PERSIST
     // persistent form: one block per CU walks the whole tiles (MODE 3: + the K-slice blocks of the tail tiles behind them)
-    if (BUF && MODE == 0 && blocks > cu_budget()) { grid = cu_budget(); Q.pgrid = grid; }
-    if (BUF && MODE == 3 && P.n_full > cu_budget()) { Q.pgrid = cu_budget(); grid = Q.pgrid + (nwg - P.n_full) * P.splits; }
+    if (g_persist && BUF && MODE == 0 && blocks > cu_budget()) { grid = cu_budget(); Q.pgrid = grid; }
+    if (g_persist && BUF && MODE == 3 && P.n_full > cu_budget()) { Q.pgrid = cu_budget(); grid = Q.pgrid + (nwg - P.n_full) * P.splits; }
 #endif
     hipLaunchKernelGGL((gemm_kernel_256<TA, TB, MODE, EPI_NONE, BUF>), dim3(grid), dim3(512), LDS_BYTES2, st, Q);
     if (MODE == 3) hipLaunchKernelGGL(tail_reduce_kernel, dim3((nwg - P.n_full) * 32), dim3(256), 0, st, P);
@@ -1174,7 +1179,7 @@ static void launch_fused1(const GemmParams& P, hipStream_t st) {
     if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_kernel_256<false, TB, 0, EPI, BUF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2); attr = true; }
     int grid = P.tiles_m * P.tiles_n;
 #ifndef RV_NO_PERSIST
-    if (BUF && grid > cu_budget()) grid = cu_budget();
+    if (g_persist && BUF && grid > cu_budget()) grid = cu_budget();
 #endif
     hipLaunchKernelGGL((gemm_kernel_256<false, TB, 0, EPI, BUF>), dim3(grid), dim3(512), LDS_BYTES2, st, P);
 }

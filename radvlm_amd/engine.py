@@ -133,6 +133,11 @@ class LlavaEngine:
         from .ddp import FlatGradSync
         # per-layer buckets (~0.4 GB bf16 for the 7B geometry): large transfers suit point-to-point xGMI links
         self.sync = FlatGradSync(self.grads, process_group) if self.world > 1 else None
+        if self.world > 1 and self.device.type == "cuda":
+            # the all-reduce kernels share the CUs with backward's GEMMs: one-tile-per-block launches lose part of a round to them, a
+            # persistent block that cannot start would delay its whole share of the tiles (rv_gemm_select_kernel, include/radvlm_hip.h)
+            from . import lib
+            lib.load().rv_gemm_select_kernel(40)
         self.ctx = None
         self.grad_accum_started = False
         self.loss_scale = 1.0
