@@ -247,20 +247,21 @@ __global__ void quick_gelu_bwd_kernel(const bf16* dy, const bf16* x, bf16* dx, l
 }
 
 // ------------------------------------------------------------------------------------------------ column sums
-// 32 columns x 8 row-lanes per 256-thread block: each lane strides the rows by 8, then one LDS hop combines them
-__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* in, int rows, int cols, bf16* out, int accumulate) {
-    __shared__ float red[8][33];
+// 32 columns x 32 row-lanes per 1024-thread block: each lane strides the rows by 32, then one LDS hop combines them (with 8 row-lanes
+// and 1024 partial rows a call took 43 us of mostly load latency: 65 calls per step)
+__global__ __launch_bounds__(1024) void colsum_f32_kernel(const float* in, int rows, int cols, bf16* out, int accumulate) {
+    __shared__ float red[32][33];
     const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
     if (c < cols)
-        for (int r = rl; r < rows; r += 8) s += in[(long)r * cols + c];
+        for (int r = rl; r < rows; r += 32) s += in[(long)r * cols + c];
     red[rl][cl] = s;
     __syncthreads();
     if (rl == 0 && c < cols) {
         float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) t += red[i][cl];
+        for (int i = 0; i < 32; ++i) t += red[i][cl];
         if (accumulate) t += bf2f(out[c]);
         out[c] = f2bf(t);
     }
@@ -830,7 +831,7 @@ extern "C" int rv_quick_gelu_bwd(const void* dy, const void* x, void* dx, int64_
 }
 extern "C" int rv_colsum_f32(const float* in, int rows, int cols, void* out, int accumulate, void* stream) {
     if (!in || !out || rows <= 0 || cols <= 0) return RV_ERR_ARG;
-    hipLaunchKernelGGL(colsum_f32_kernel, dim3(nblocks(cols, 32)), dim3(256), 0, ST, in, rows, cols, (bf16*)out, accumulate);
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3(nblocks(cols, 32)), dim3(1024), 0, ST, in, rows, cols, (bf16*)out, accumulate);
     return rv_check_launch();
 }
 extern "C" int rv_colsum_partial_bf16(const void* x, int64_t ld, int rows, int cols, float* partial, int nblk, void* stream) {
