@@ -178,6 +178,28 @@ def test_lora_run_saves_the_reference_files_and_resumes(tmp_path):
         conv_lib.default_conversation = conv_lib.conv_templates["v1"]
 
 
+def test_save_only_model_checkpoints_and_their_resume(tmp_path):
+    """--save_only_model True (HF TrainingArguments.save_only_model): checkpoint-N holds the weights and the trainer state but no optimizer
+    state (81 GB at 7B); a run resumed from it continues at step N + 1 with a fresh AdamW (moments zero, bias correction from step 1)."""
+    _need_gpu()
+    from radvlm_amd.llava import conversation as conv_lib
+    from radvlm_amd.llava.train.train import train
+    data = _dataset(tmp_path, n=8)
+    common = ["--geometry", "toy", "--save_steps", "2", "--save_only_model", "True"]
+    try:
+        train(argv=_train_args(tmp_path, data, common + ["--max_steps", "3", "--output_dir", str(tmp_path / "a")]), tokenizer=Tok())
+        ck = set(os.listdir(tmp_path / "a" / "checkpoint-2"))
+        assert "model.safetensors" in ck and "trainer_state.json" in ck and "optimizer.safetensors" not in ck
+        st = train(argv=_train_args(tmp_path, data, common + ["--max_steps", "4", "--output_dir", str(tmp_path / "a")]), tokenizer=Tok())
+        assert [r["step"] for r in st["log_history"]] == [1, 2, 3, 4]
+        assert all(np.isfinite(r["loss"]) for r in st["log_history"])
+        # with its optimizer state a checkpoint is larger and resumes the moments (the default)
+        train(argv=_train_args(tmp_path, data, ["--geometry", "toy", "--save_steps", "2", "--max_steps", "2", "--output_dir", str(tmp_path / "b")]), tokenizer=Tok())
+        assert "optimizer.safetensors" in os.listdir(tmp_path / "b" / "checkpoint-2")
+    finally:
+        conv_lib.default_conversation = conv_lib.conv_templates["v1"]
+
+
 @pytest.mark.parametrize("packed", ["auto", False])
 def test_left_padding_against_reference_golden(golden_dir, packed):
     """config.tokenizer_padding_side = 'left' (llava_arch.py:520-524) against a reference-generated fixture: splice labels / mask
