@@ -206,6 +206,10 @@ def main():
     ap.add_argument("--packed", default="auto", choices=["auto", "0", "1"], help="packed (varlen) decoder batches")
     ap.add_argument("--reserved-cus", type=int, default=None,
                     help="compute units the GEMM round planning leaves to the overlapped RCCL all-reduce (default 0: the collectives are active for a small part of backward only)")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="N = 1 only: create the nccl (= RCCL) process group of one rank and issue every gradient bucket's all-reduce on the "
+                         "side stream anyway (single-GPU rehearsal of the N > 1 path: stream / event ordering, one-tile GEMM blocks beside the "
+                         "collectives).  Not the headline configuration.")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -239,6 +243,16 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     pg = None
+    force_pg = args.force_process_group and world == 1
+    if force_pg:
+        import socket
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+        pg = torch.distributed.group.WORLD
     if world > 1:
         if rehearsal:
             torch.distributed.init_process_group("gloo")
@@ -246,7 +260,7 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
         pg = torch.distributed.group.WORLD
     ranks_seen, backend = 1, None
-    if world > 1:
+    if world > 1 or force_pg:
         seen = torch.zeros(world, dtype=torch.int32, device=f"cuda:{local}")
         seen[rank] = 1
         torch.distributed.all_reduce(seen)
@@ -266,7 +280,7 @@ def main():
         kw = dict(merge_type="spatial_unpad", image_aspect_ratio="anyres_max_9", image_grid_pinpoints="(1x1),...,(6x6)",
                   train_vision_tower=True)
     kw["packed"] = {"auto": "auto", "0": False, "1": True}[args.packed]
-    eng = LlavaEngine(geo, device=f"cuda:{local}", init="fast", seed=0, process_group=pg, **kw)
+    eng = LlavaEngine(geo, device=f"cuda:{local}", init="fast", seed=0, process_group=pg, force_grad_sync=force_pg, **kw)
     eng.init_optimizer()
     make = {"anyres": synthetic_batch_anyres, "radvlm": synthetic_batch_radvlm}.get(args.workload, synthetic_batch)
     if args.text_lens and args.workload == "cxr":
@@ -377,14 +391,14 @@ def main():
                        **({"text_lens": args.text_lens, "packed": args.packed} if args.text_lens else {})},
             "roofline": roofline,
             "distributed": {"world": world, "ranks_seen": ranks_seen, "backend": backend if not rehearsal else f"{backend} (rehearsal: all ranks on one GPU)",
-                            "grad_sync": None if world == 1 else "bucketed sum-all-reduce of the flat bf16 gradient buffer, per-layer buckets on a side stream",
+                            "grad_sync": None if eng.sync is None else "bucketed sum-all-reduce of the flat bf16 gradient buffer, per-layer buckets on a side stream",
                             "exposed_comm_ms_per_step": comm_wait_ms, "gemm_cu_budget": cu_budget, "reserved_cus": reserved},
             "build": {"kernel_source_sha256": src_hash},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(geo)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_pg:
         torch.distributed.destroy_process_group()
 
 

@@ -120,10 +120,14 @@ def load_pretrained(engine, lm_path=None, tower_path=None, allow_missing=("model
                 if t.ndim == 2 and t.shape[0] < dst.shape[0] and tuple(t.shape[1:]) == tuple(dst.shape[1:]):
                     dst[:t.shape[0]].copy_(t.to(dst.dtype))      # vocabulary tables padded to a multiple of 8 rows
                     dst[t.shape[0]:].zero_()
-                elif tuple(t.shape) != tuple(dst.shape) and t.numel() != dst.numel():
-                    raise ValueError(f"{name}: checkpoint shape {tuple(t.shape)} does not match the model's {tuple(dst.shape)}")
-                else:
+                elif tuple(t.shape) == tuple(dst.shape):
+                    dst.copy_(t.to(dst.dtype))
+                elif t.numel() == dst.numel() and (t.ndim == 1 or dst.ndim == 1 or (t.ndim == 4 and dst.ndim == 2 and t.shape[0] == dst.shape[0])):
+                    # the only reshapes a checkpoint may need: the conv patch embedding [d,3,p,p] -> [d,3*p*p] and 1-D tensors stored
+                    # with a unit axis; any other same-size shape (a transposed or fused projection) would load as wrong weights
                     dst.copy_(t.to(dst.dtype).reshape(dst.shape))
+                else:
+                    raise ValueError(f"{name}: checkpoint shape {tuple(t.shape)} does not match the model's {tuple(dst.shape)}")
                 hit = True
         if hit:
             seen.add(name)

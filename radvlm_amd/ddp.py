@@ -12,12 +12,15 @@ import torch.distributed as dist
 
 
 class FlatGradSync:
-    def __init__(self, flat_grads, process_group=None, min_bucket_elems=0):
+    def __init__(self, flat_grads, process_group=None, min_bucket_elems=0, force=False):
         self.flat = flat_grads
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
         self.on_gpu = flat_grads.is_cuda
-        self.stream = torch.cuda.Stream(device=flat_grads.device) if (self.on_gpu and self.world > 1) else None
+        # force: issue the per-bucket collectives even in a group of one rank -- the single-GPU rehearsal of the RCCL path (same
+        # stream / event ordering, same launches next to backward's GEMMs; a one-rank all-reduce leaves the data unchanged)
+        self.active = self.world > 1 or bool(force)
+        self.stream = torch.cuda.Stream(device=flat_grads.device) if (self.on_gpu and self.active) else None
         self.pending = []
         self.min_bucket = min_bucket_elems
         self._lo = self._hi = None
@@ -26,7 +29,7 @@ class FlatGradSync:
 
     def bucket_done(self, start, end):
         """Elements [start, end) are final. Adjacent ready ranges are coalesced until >= min_bucket_elems."""
-        if self.world == 1:
+        if not self.active:
             return
         if self._lo is None:
             self._lo, self._hi = start, end

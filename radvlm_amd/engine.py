@@ -34,7 +34,7 @@ class LlavaEngine:
     def __init__(self, geo, device="cuda", merge_type="flat", image_aspect_ratio="square", image_grid_pinpoints=None,
                  max_len=None, init="portable", seed=0, rms_eps=1e-5, rope_theta=10000.0, process_group=None,
                  bucket_layers=1, train_vision_tower=False, lora=None, packed="auto", freeze_lm=False, train_embed_tokens=False,
-                 padding_side="right"):
+                 padding_side="right", force_grad_sync=False):
         self.geo = geo
         # packed (varlen) decoder batches: True / False / "auto" (pack when the samples of a batch differ in length): the decoder
         # then runs on sum(len_b) token rows instead of B * max(len_b) -- no padding rows through GEMMs, norms, CE
@@ -132,8 +132,10 @@ class LlavaEngine:
         self.bucket_layers = bucket_layers
         from .ddp import FlatGradSync
         # per-layer buckets (~0.4 GB bf16 for the 7B geometry): large transfers suit point-to-point xGMI links
-        self.sync = FlatGradSync(self.grads, process_group) if self.world > 1 else None
-        if self.world > 1 and self.device.type == "cuda":
+        # force_grad_sync: a one-rank group still issues every bucket's collective (single-GPU rehearsal of the RCCL path)
+        self.force_grad_sync = bool(force_grad_sync) and process_group is not None
+        self.sync = FlatGradSync(self.grads, process_group, force=self.force_grad_sync) if (self.world > 1 or self.force_grad_sync) else None
+        if self.sync is not None and self.device.type == "cuda":
             # the all-reduce kernels share the CUs with backward's GEMMs: one-tile-per-block launches lose part of a round to them, a
             # persistent block that cannot start would delay its whole share of the tiles (rv_gemm_select_kernel, include/radvlm_hip.h)
             from . import lib
@@ -192,9 +194,9 @@ class LlavaEngine:
             self.master = self.m = self.vv = None
             self.opt_step = 0
             self.grad_accum_started = False
-            if self.world > 1:
+            if self.sync is not None:
                 from .ddp import FlatGradSync
-                self.sync = FlatGradSync(self.grads, self.pg)
+                self.sync = FlatGradSync(self.grads, self.pg, force=self.force_grad_sync)
         self.weights_changed()
 
     # ------------------------------------------------------------------ weights
@@ -235,8 +237,11 @@ class LlavaEngine:
             self._vis_pad = {}
 
     def _stat_buffer(self, key, B, H, s_pad):
-        """Zero-initialised fp32 [B, H, s_pad] softmax-statistics buffers (lse per layer, delta), allocated once and reused every step:
-        the kernels overwrite the valid entries, the padding entries are never written and stay zero -- no fill kernel per layer."""
+        """fp32 [B, H, s_pad] softmax-statistics buffers (lse per layer, delta), allocated once (zeroed) and reused every step: the
+        kernels overwrite the entries of valid rows only -- no fill kernel per layer.  With ragged data a later batch of the same padded
+        shape but shorter samples therefore sees STALE lse / delta in rows >= len; that is harmless by construction, not by zeroing:
+        the dK/dV edge tiles select p = 0 for query rows >= q_end before any use of lse / delta, and the dQ pass reads them only for
+        rows < len (tests/test_train_features_gpu.py::test_stale_softmax_statistics_are_masked)."""
         k = (key, B, H, s_pad)
         buf = self._stats.get(k)
         if buf is None:
@@ -250,9 +255,9 @@ class LlavaEngine:
         stream first, i.e. the host could never enqueue ahead of the GPU (each of the ~10 index uploads of a step was such a wait: any host
         hiccup then idled the GPU); torch's pinned-memory cache recycles a block only after the copy that used it has finished."""
         t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
-        if self.device.type != "cuda":
+        if self.device.type != "cuda" or t.device.type != "cpu":
             return t.to(self.device)
-        return t.pin_memory().to(self.device, non_blocking=True)
+        return (t if t.is_pinned() else t.pin_memory()).to(self.device, non_blocking=True)
 
     def rope_table(self, S):
         if S not in self._rope:
@@ -520,7 +525,9 @@ class LlavaEngine:
         plan = self.plan(input_ids, attention_mask, labels, images, image_sizes)
         self.lora_step += 1
         pix = torch.cat([(im if im.ndim == 4 else im[None]) for im in images], 0)
-        pix = (pix if pix.is_pinned() else pix.pin_memory()).to(dev, non_blocking=True)     # pinned: the copy does not stall the stream
+        if pix.device.type == "cpu" and not pix.is_pinned() and dev.type == "cuda":
+            pix = pix.pin_memory()                                                          # pinned: the copy does not stall the stream
+        pix = pix.to(dev, non_blocking=True)          # images already on the device (HF Trainer._prepare_inputs moves them) pass through
         if pix.dtype == torch.uint8:
             # device-side normalisation: uint8 HWC tiles from the host (resize / crop / pad only), rescale + (x - mean) / std
             # + channel-first layout + bf16 cast here, in the processors' own fp32 arithmetic

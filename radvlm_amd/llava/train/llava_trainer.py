@@ -164,11 +164,13 @@ def lr_at(update, total_steps, base_lr, warmup_steps, kind="cosine"):
     s = update - 1
     if kind == "cosine":
         return cosine_lr(s, total_steps, base_lr, warmup_steps)
+    if kind == "constant":       # HF get_constant_schedule: no warm-up (only constant_with_warmup has one)
+        return base_lr
     if s < warmup_steps:
         return base_lr * s / max(1, warmup_steps)
     if kind == "linear":
         return base_lr * max(0.0, (total_steps - s) / max(1, total_steps - warmup_steps))
-    if kind in ("constant", "constant_with_warmup"):
+    if kind == "constant_with_warmup":
         return base_lr
     raise ValueError(f"lr_scheduler_type {kind!r}: cosine, linear, constant and constant_with_warmup are built")
 

@@ -50,3 +50,16 @@ def test_self_spawned_two_rank_line():
     d = _run(["--gpus", "2"], env={"RV_BENCH_REHEARSAL": "1"})
     _check(d, 2)
     assert "gloo" in d["distributed"]["backend"] and d["distributed"]["exposed_comm_ms_per_step"] >= 0.0
+
+
+def test_rccl_branch_runs_in_a_one_rank_group():
+    """The `nccl` (= RCCL) branch on the one GPU a test box has: `init_process_group("nccl", world_size=1)` before any other GPU call,
+    every gradient bucket's all-reduce issued on the side stream next to backward's GEMMs (one-tile GEMM blocks,
+    rv_gemm_select_kernel(40), as for N > 1), the compute stream joined with it before the optimizer.  A one-rank all-reduce leaves the
+    gradients unchanged, so the loss trajectory must equal the plain single-GPU run's bit for bit."""
+    d0 = _run([])
+    d = _run(["--force-process-group"])
+    _check(d, 1)
+    assert d["distributed"]["backend"] == "nccl" and d["distributed"]["exposed_comm_ms_per_step"] >= 0.0
+    assert d["distributed"]["grad_sync"] is not None
+    assert d["config"]["final_loss"] == d0["config"]["final_loss"], (d["config"]["final_loss"], d0["config"]["final_loss"])

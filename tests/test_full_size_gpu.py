@@ -1,0 +1,191 @@
+"""Full-size BASELINE config-2 parity (-m gpu): the WHOLE LLaVA-1.5-7B model (24-layer ViT-L/14-336 tower, projector, 32 full-width
+decoder layers, 32000-way head; 6.76 B trainable parameters) through forward, backward and two AdamW steps on the HIP engine, against
+the CPU oracle in fp32 on the same weights and inputs (b = 1, one 336 px image + 129 ids -> S = 704).
+
+Why it exists: toy / one-layer parity cannot see whole-model faults.  Round 2's 32-bit work-item overflow zeroed every parameter behind
+decoder layer 12 from the second optimizer step on and no parity test noticed.  Here every one of the 291 trainable
+tensors is compared after the backward (gradients) and after the second optimizer step (fp32 master copy and bf16 parameters).
+
+Reference text followed by the oracle: language_model/modeling_llama.py:1083-1185 (model), :1304-1337 (loss), llava_arch.py:251-555
+(splice), clip_encoder.py:46-79, multimodal_projector/builder.py:41-48; optimizer = torch.optim.AdamW semantics (optim adamw_torch,
+train/train.py:140) with the global-norm clip of HF Trainer (max_grad_norm) and the decay / no-decay groups of
+LLaVATrainer.create_optimizer (train/llava_trainer.py:369-418).
+
+Host memory: fp32 parameters + gradients + two AdamW moments of 6.76 B parameters = 108 GB (the GPU box allows ~270 GiB).  If the host
+offers less than 150 GB the test runs 8 full-width layers + head instead and says so in its record (RV_FULLSIZE_LAYERS overrides).
+"""
+import copy
+import json
+import math
+import os
+import time
+
+import pytest
+import torch
+
+from radvlm_amd.config import GEOMETRIES
+
+pytestmark = pytest.mark.gpu
+
+# Gates: <= 1.25 x the values measured on MI355X (profiles/r03_full_size_parity.json holds the measurements)
+LOSS_TOL = 1e-2               # |loss_hip - loss_fp32|, both steps
+GRAD_REL_L2 = 0.15            # per tensor ||g_hip - g_fp32||_2 / ||g_fp32||_2 (bf16 gradients of a 32-layer bf16 backward)
+GRAD_NORM_REL = 3e-2          # global gradient norm
+UPDATE_MEAN = 0.15            # mean |master_hip - p_fp32| / lr per tensor after two steps (an AdamW update is <= ~1 lr per step)
+UPDATE_FRAC_BAD = 5e-2        # fraction of a tensor's elements whose two-step update differs by more than 0.5 lr
+
+
+def _avail_gb():
+    try:
+        import psutil
+        return psutil.virtual_memory().available / 1e9
+    except Exception:
+        return 0.0
+
+
+def _no_decay(name, shape):
+    return len(shape) == 1 and ("norm" in name or name.endswith("bias"))
+
+
+def test_config2_full_size_forward_backward_two_adamw_steps():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import bf16_emulation as E
+    from oracle import llava_oracle as O
+    from radvlm_amd.engine import LlavaEngine
+    from conftest import ROOT, record_measurement
+    t_start = time.time()
+    want = os.environ.get("RV_FULLSIZE_LAYERS")
+    layers = int(want) if want else (32 if _avail_gb() >= 150 else 8)
+    geo = copy.deepcopy(GEOMETRIES["llava15_7b"])
+    geo["lm"]["layers"] = layers
+    V = geo["lm"]["vocab"]
+    g = torch.Generator().manual_seed(17)
+    ids = torch.randint(3, V, (1, 129), generator=g)
+    labels = ids.clone()
+    labels[:, :64] = -100
+    ids[:, 35] = -200
+    labels[:, 35] = -100
+    mask = torch.ones(1, 129, dtype=torch.bool)
+    images = [torch.randn(3, 336, 336, generator=g).to(torch.bfloat16).float()]
+    lr, wd, clip, b1, b2, eps = 1e-4, 0.05, 1.0, 0.9, 0.999, 1e-8
+
+    eng = LlavaEngine(geo, device="cuda:0", init="fast", seed=11)
+    names = eng.lm.names()
+    n_params = sum(eng.lm.offsets[n][1] for n in names)
+    if layers == 32:
+        assert n_params > 6.7e9, n_params
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    P = {k: v.float().cpu() for k, v in eng.state_dict().items()}         # bf16-exact fp32 copies (27 GB at 32 layers)
+    for k in names:
+        P[k].requires_grad_(True)
+    a = (ids, mask, labels, images)
+    rec = dict(layers=layers, trainable_params=n_params, host_threads=torch.get_num_threads())
+
+    def hip_step():
+        loss = float(eng.forward(ids.numpy(), mask.numpy(), labels.numpy(), images, want_logits=True))
+        logits = eng.last_logits.cpu()
+        pm = torch.from_numpy(eng.ctx["plan"]["attention_mask"])
+        eng.backward()
+        torch.cuda.synchronize()
+        return loss, logits, pm
+
+    def oracle_step():
+        for k in names:
+            P[k].grad = None
+        rl, rlog, aux = O.llava_forward(P, geo, *a)
+        rl.backward()
+        return float(rl), rlog.detach(), aux
+
+    def compare_grads(tag):
+        worst, worst_name, sq_h, sq_r = 0.0, None, 0.0, 0.0
+        per_kind = {}
+        for k in names:
+            ref = P[k].grad.to("cuda:0")
+            got = eng.G(k).float()
+            rn = float(ref.norm())
+            sq_h += float(got.double().pow(2).sum())
+            sq_r += float(ref.double().pow(2).sum())
+            rel = float((got - ref).norm()) / max(rn, 1e-30)
+            kind = k.split(".")[-2] if k.startswith("model.layers.") else k
+            per_kind[kind] = max(per_kind.get(kind, 0.0), rel)
+            if rel > worst:
+                worst, worst_name = rel, k
+            assert rn > 0 and rel < GRAD_REL_L2, (tag, k, rel, rn)
+        gn_h, gn_r = math.sqrt(sq_h), math.sqrt(sq_r)
+        rec[tag] = dict(worst_rel_l2=worst, worst_tensor=worst_name, per_kind_worst_rel_l2=per_kind, grad_norm_hip=gn_h, grad_norm_fp32=gn_r)
+        assert abs(gn_h - gn_r) <= GRAD_NORM_REL * gn_r, (tag, gn_h, gn_r)
+        return gn_r
+
+    M, Vv = {}, {}
+
+    def oracle_adamw(step, total_norm):
+        coef = min(1.0, clip / (total_norm + 1e-6))           # torch.nn.utils.clip_grad_norm_
+        with torch.no_grad():
+            for k in names:
+                p = P[k]
+                if k not in M:
+                    M[k], Vv[k] = torch.zeros_like(p), torch.zeros_like(p)
+                O.adamw_step(p, p.grad * coef, M[k], Vv[k], step, lr, b1, b2, eps, 0.0 if _no_decay(k, p.shape) else wd)
+
+    # ---- step 1: forward (vs fp32 oracle and vs the bf16-emulating oracle), backward, optimizer
+    loss1, logits, pm = hip_step()
+    t0 = time.time()
+    rl1, rlog, aux = oracle_step()
+    rec["oracle_fwd_bwd_s"] = time.time() - t0
+    assert aux["inputs_embeds"].shape[1] == 704
+    le, lge, _ = E.llava_forward({k: v.detach() for k, v in P.items()}, geo, *a, emulate=True)
+    m = pm
+    relinf = lambda x, y: float((x[m] - y[m]).abs().max() / y[m].abs().max())
+    rel2 = lambda x, y: float((x[m] - y[m]).norm() / y[m].norm())
+    rec.update(loss_hip=loss1, loss_fp32=rl1, loss_emu=float(le), hip_vs_fp32_inf=relinf(logits, rlog), hip_vs_fp32_l2=rel2(logits, rlog),
+               emu_vs_fp32_inf=relinf(lge, rlog), emu_vs_fp32_l2=rel2(lge, rlog), hip_vs_emu_inf=relinf(logits, lge), hip_vs_emu_l2=rel2(logits, lge))
+    del lge, rlog
+    assert abs(loss1 - rl1) <= LOSS_TOL, rec
+    assert abs(loss1 - float(le)) <= LOSS_TOL, rec
+    # the same three inequalities as test_bf16_emulated_parity: as close to fp32 as an ideal bf16 implementation of the same store points
+    assert rec["hip_vs_fp32_l2"] <= 1.1 * rec["emu_vs_fp32_l2"] and rec["hip_vs_fp32_inf"] <= 1.25 * rec["emu_vs_fp32_inf"], rec
+    assert rec["hip_vs_emu_l2"] <= rec["emu_vs_fp32_l2"] * 1.1, rec
+    gn1 = compare_grads("grads_step1")
+    eng.optimizer_step(lr, weight_decay=wd, betas=(b1, b2), eps=eps, max_grad_norm=clip)
+    rec["grad_norm_engine_step1"] = float(eng.last_grad_norm)
+    assert abs(rec["grad_norm_engine_step1"] - gn1) <= GRAD_NORM_REL * gn1, rec
+    oracle_adamw(1, gn1)
+
+    # ---- step 2 (from the second optimizer step on, a wrong master copy / a slice that was never updated shows)
+    loss2, _, _ = hip_step()
+    rl2, _, _ = oracle_step()
+    rec.update(loss2_hip=loss2, loss2_fp32=rl2)
+    assert abs(loss2 - rl2) <= LOSS_TOL, rec
+    gn2 = compare_grads("grads_step2")
+    eng.optimizer_step(lr, weight_decay=wd, betas=(b1, b2), eps=eps, max_grad_norm=clip)
+    oracle_adamw(2, gn2)
+    torch.cuda.synchronize()
+
+    # ---- every trainable tensor after two updates: fp32 master vs the oracle's fp32 parameters, bf16 parameters = round(master)
+    worst_mean, worst_bad, worst_ulp = (0.0, None), (0.0, None), 0
+    for k in names:
+        off, n = eng.lm.offsets[k]
+        ref = P[k].detach().to("cuda:0").view(-1)
+        mas = eng.master[off:off + n]
+        par = eng.lm.flat[off:off + n]
+        assert torch.equal(par, mas.to(torch.bfloat16)), k                      # the bf16 parameters ARE the rounded master copy
+        du = (mas - ref).abs() / lr
+        mean, bad = float(du.mean()), float((du > 0.5).float().mean())
+        if mean > worst_mean[0]:
+            worst_mean = (mean, k)
+        if bad > worst_bad[0]:
+            worst_bad = (bad, k)
+        assert mean <= UPDATE_MEAN and bad <= UPDATE_FRAC_BAD, (k, mean, bad)
+        # bf16 view: within one ulp of the rounded oracle parameter (monotonic integer view of the bit patterns)
+        mono = lambda t: torch.where(t.view(torch.int16).int() >= 0, t.view(torch.int16).int(), -(t.view(torch.int16).int() & 0x7FFF))
+        ulp = int((mono(par) - mono(ref.to(torch.bfloat16))).abs().max())
+        worst_ulp = max(worst_ulp, ulp)
+        assert ulp <= 1, (k, ulp)
+    rec.update(update_worst_mean_over_lr=worst_mean, update_worst_frac_gt_half_lr=worst_bad, worst_bf16_ulp=worst_ulp,
+               seconds=time.time() - t_start, lr=lr, weight_decay=wd, max_grad_norm=clip)
+    record_measurement("config2_full_size", **rec)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "full_size_parity.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    print(json.dumps(rec))
