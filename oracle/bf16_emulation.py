@@ -207,3 +207,122 @@ def llava_forward(P, geo, input_ids, attention_mask, labels, images, image_sizes
         stored, logits = llama_forward(P, geo, E, lens, rnd)
         loss = O.causal_lm_loss(stored, L)       # the loss reads the bf16-stored logits (modeling_llama.py:1324 logits.float())
     return loss, logits, dict(inputs_embeds=E, labels=L, attention_mask=M, lens=lens, image_features=feats)
+
+
+# ----------------------------------------------------------------------------- backward of one decoder layer, HIP store points
+# The forward above shadows the reference's forward; its backward is what torch autograd derives from modeling_llama.py:852-911
+# (decoder layer), :82-87 (RMSNorm), :174-198 (rotary embedding), :349-368 (attention) and :226 (SwiGLU).  The functions below are
+# those derivatives written out op by op, in fp32, with a bf16 rounding exactly where the HIP backward STORES bf16:
+#   every dgrad GEMM output (one rounding; "+ dx" of the norm backward is inside the same store)
+#   SwiGLU backward            d(act) rounded (it was a tensor of the unfused sequence and the fused epilogue keeps that point), then
+#                              d gate / d up rounded once
+#   attention backward         P and dS rounded before the P^T dO / dS K / dS^T Q products (MFMA operands), dQ / dK rounded before the
+#                              rotary adjoint (the unfused sequence stored them first), one more rounding after it; dV rounded once;
+#                              grouped-query heads: the group's query heads are summed in fp32 before the rounding
+#   weight gradients           returned as fp32 sums (the GEMM's fp32 accumulators; the bf16 store into the flat gradient buffer is one
+#                              rounding of these)
+# Pinning: with rnd = identity `decoder_layer_backward` must equal torch autograd of llava_oracle.decoder_layer to 1e-5
+# (tests/test_oracle_golden.py::test_bf16_emulation_backward_reduces_to_autograd).
+def swiglu_bwd(dact, gu, F_, rnd):
+    g, u = gu[..., :F_], gu[..., F_:]
+    d = rnd(dact)
+    sg = torch.sigmoid(g)
+    return torch.cat((rnd(d * u * (sg * (1.0 + g * (1.0 - sg)))), rnd(d * (g * sg))), -1)
+
+
+def rmsnorm_bwd(dy, x, w, eps, dx_in, rnd):
+    """d/dx of w * (x * rstd): returns (rnd(dx_in + dx), fp32 dw).  dw sums dy * (x * rstd) over rows."""
+    rstd = torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps)
+    xh = x * rstd
+    gg = dy * w
+    dot = (gg * xh).mean(-1, keepdim=True)
+    dx = rstd * (gg - xh * dot)
+    return rnd((dx_in if dx_in is not None else 0.0) + dx), (dy * xh).reshape(-1, x.shape[-1]).sum(0)
+
+
+def unrope(x, cos, sin, rnd):
+    """Adjoint of `rope` (a rotation: its transpose); x [b,h,S,hd] rounded first, rounded once more after."""
+    h = x.shape[-1] // 2
+    a, b = rnd(x[..., :h]), rnd(x[..., h:])
+    return rnd(torch.cat((a * cos + b * sin, b * cos - a * sin), dim=-1))
+
+
+def attention_lse(q, k, lens, scale):
+    """Natural-log softmax normaliser of the causal + key-padding masked scores, [b,h,S] (what the forward kernel leaves for backward)."""
+    b, h, S, hd = q.shape
+    nrep = h // k.shape[1]
+    s = torch.matmul(q, k.repeat_interleave(nrep, dim=1).transpose(2, 3)) * scale
+    ok = torch.tril(torch.ones(S, S, dtype=torch.bool))[None, None]
+    if lens is not None:
+        ok = ok & (torch.arange(S)[None, None, None, :] < torch.as_tensor(lens)[:, None, None, None])
+    return torch.logsumexp(s.masked_fill(~ok, -math.inf), dim=-1)
+
+
+def attention_bwd(q, k, v, o, do, lse, lens, scale, rnd, cos=None, sin=None, group_partials_bf16=False):
+    """q, o, do [b,h,S,hd]; k, v [b,kvh,S,hd] (q, k rotated); lse [b,h,S].  Returns (dq, dk, dv) as the kernels store them: gradients of
+    the UN-rotated q / k when cos / sin are given.  group_partials_bf16: the grouped-query launch shape that writes one bf16 dK / dV
+    partial per QUERY head and sums the group afterwards (rv_attn_bwd_nat with a workspace and a small grid) -- one more store point."""
+    b, h, S, hd = q.shape
+    kvh = k.shape[1]
+    nrep = h // kvh
+    kk, vv = k.repeat_interleave(nrep, dim=1), v.repeat_interleave(nrep, dim=1)
+    ok = torch.tril(torch.ones(S, S, dtype=torch.bool))[None, None]
+    if lens is not None:
+        ln = torch.as_tensor(lens)[:, None, None, None]
+        ok = ok & (torch.arange(S)[None, None, None, :] < ln) & (torch.arange(S)[None, None, :, None] < ln)
+    sl2 = scale * LOG2E
+    p = torch.exp2(torch.matmul(q, kk.transpose(2, 3)) * sl2 - (lse * LOG2E)[..., None])
+    p = torch.where(ok, p, torch.zeros_like(p))
+    delta = (do * o).sum(-1, keepdim=True)
+    ds = p * (torch.matmul(do, vv.transpose(2, 3)) - delta)
+    pr, dsr = rnd(p), rnd(ds)
+    dq = torch.matmul(dsr, kk) * scale
+    part = rnd if (group_partials_bf16 and nrep > 1) else identity
+    dk = part(torch.matmul(dsr.transpose(2, 3), q) * scale).view(b, kvh, nrep, S, hd).sum(2)
+    dv = part(torch.matmul(pr.transpose(2, 3), do)).view(b, kvh, nrep, S, hd).sum(2)
+    if cos is not None:
+        return unrope(dq, cos, sin, rnd), unrope(dk, cos, sin, rnd), rnd(dv)
+    return rnd(dq), rnd(dk), rnd(dv)
+
+
+def decoder_layer_backward(T, P, pre, l, lens, dx_out, rnd, rope_adjoint=True, group_partials_bf16=False):
+    """Backward of `decoder_layer` through the stored activations T (a TRACE of the forward: bf16-exact when rnd = bf16_round) for the
+    upstream gradient dx_out [b,S,d].  Returns an ordered dict: every tensor the HIP backward stores for this layer, in its order --
+      gW_down, dgu, gW_gu, dh2, dx_mid, g_ln2, gW_o, dattn, dqkv (un-rotated q|k|v gradient), g_bqkv, gW_qkv, dh1, dx_in, g_ln1
+    (gW_* / g_* in fp32).  Each op reads the previous op's STORED output, so every entry is also the exact input of the next op."""
+    from collections import OrderedDict
+    d, F_ = l["d"], l["ffn"]
+    heads, kvh = l["heads"], l.get("kv_heads", l["heads"])
+    hd = d // heads
+    eps = l.get("rms_eps", 1e-5)
+    b, S, _ = dx_out.shape
+    flat = lambda t: t.reshape(-1, t.shape[-1])
+    W = lambda n: P[pre + n]
+    out = OrderedDict()
+    x, h1, attn, x_mid, h2, gu, act = (T[pre + n] for n in ("x", "h1", "attn", "x_mid", "h2", "gu", "act"))
+    out["gW_down"] = flat(dx_out).t().double().matmul(flat(act).double()).float()
+    out["dgu"] = dgu = swiglu_bwd(F.linear(dx_out, W("mlp.down_proj.weight").t()), gu, F_, rnd)
+    wgu = torch.cat((W("mlp.gate_proj.weight"), W("mlp.up_proj.weight")), 0)
+    out["gW_gu"] = flat(dgu).t().double().matmul(flat(h2).double()).float()
+    out["dh2"] = dh2 = rnd(F.linear(dgu, wgu.t()))
+    out["dx_mid"], out["g_ln2"] = rmsnorm_bwd(dh2, x_mid, W("post_attention_layernorm.weight"), eps, dx_out, rnd)
+    dx_mid = out["dx_mid"]
+    out["gW_o"] = flat(dx_mid).t().double().matmul(flat(attn).double()).float()
+    out["dattn"] = dattn = rnd(F.linear(dx_mid, W("self_attn.o_proj.weight").t()))
+    heads_of = lambda t, n: t.view(b, S, n, hd).transpose(1, 2)
+    q, k, v = heads_of(T[pre + "q_roped"], heads), heads_of(T[pre + "k_roped"], kvh), heads_of(T[pre + "v"], kvh)
+    inv = 1.0 / (l.get("rope_theta", 10000.0) ** (torch.arange(0, hd, 2, dtype=torch.int64).float() / hd))
+    fr = torch.outer(torch.arange(S, dtype=torch.float32), inv)
+    cos, sin = rnd(fr.cos()), rnd(fr.sin())
+    scale = 1.0 / math.sqrt(hd)
+    out["lse"] = lse = attention_lse(q, k, lens, scale)
+    dq, dk, dv = attention_bwd(q, k, v, heads_of(attn, heads), heads_of(dattn, heads), lse, lens, scale, rnd,
+                               cos if rope_adjoint else None, sin if rope_adjoint else None, group_partials_bf16)
+    back = lambda t: t.transpose(1, 2).reshape(b, S, -1)
+    out["dqkv"] = dqkv = torch.cat((back(dq), back(dk), back(dv)), -1)
+    out["g_bqkv"] = flat(dqkv).sum(0)
+    wqkv = torch.cat((W("self_attn.q_proj.weight"), W("self_attn.k_proj.weight"), W("self_attn.v_proj.weight")), 0)
+    out["gW_qkv"] = flat(dqkv).t().double().matmul(flat(h1).double()).float()
+    out["dh1"] = dh1 = rnd(F.linear(dqkv, wqkv.t()))
+    out["dx_in"], out["g_ln1"] = rmsnorm_bwd(dh1, x, W("input_layernorm.weight"), eps, dx_mid, rnd)
+    return out

@@ -34,8 +34,10 @@ class LlavaEngine:
     def __init__(self, geo, device="cuda", merge_type="flat", image_aspect_ratio="square", image_grid_pinpoints=None,
                  max_len=None, init="portable", seed=0, rms_eps=1e-5, rope_theta=10000.0, process_group=None,
                  bucket_layers=1, train_vision_tower=False, lora=None, packed="auto", freeze_lm=False, train_embed_tokens=False,
-                 padding_side="right", force_grad_sync=False):
+                 padding_side="right", force_grad_sync=False, recompute=False):
         self.geo = geo
+        assert recompute in (False, True, "auto")
+        self.recompute = recompute            # activation recompute policy of the decoder layers (_recompute_layers)
         # packed (varlen) decoder batches: True / False / "auto" (pack when the samples of a batch differ in length): the decoder
         # then runs on sum(len_b) token rows instead of B * max(len_b) -- no padding rows through GEMMs, norms, CE
         self.packed = packed
@@ -514,6 +516,71 @@ class LlavaEngine:
                 adj_pos=(n_proj + order // 4).astype(np.int32), adj_w=w[order], adj_out=usrc.astype(np.int32))
         return plan
 
+    # ------------------------------------------------------------------ decoder layer
+    def activation_bytes_per_row(self):
+        """bf16 bytes one decoder layer keeps per token row for backward: x, h1, q|k|v, attn, x_mid, h2, gate|up, act (+ fp32 statistics)."""
+        d, F = self.l["d"], self.l["ffn"]
+        return 2 * (6 * d + 2 * self.kvd + 3 * F) + 4 * (2 + self.l["heads"])
+
+    def _recompute_layers(self, M):
+        """How many decoder layers (the first n) re-run their forward in backward.  False: none -- the activations of all layers stay
+        resident (~95 GB for 32 pairs x 704 tokens of the 7B model: what 288 GB of HBM are for); True: all; "auto": as few as the free
+        device memory requires (one 32k-token sample of the reference recipe, finetune_radio_7b.sh:79, needs ~140 GB of activations on
+        top of 108 GB of parameter / optimizer state)."""
+        L = self.l["layers"]
+        if self.recompute is True:
+            return L
+        if not self.recompute or self.device.type != "cuda":
+            return 0
+        per_layer = M * self.activation_bytes_per_row()
+        free, _ = torch.cuda.mem_get_info(self.device)
+        free += torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)     # torch's cached, unused blocks
+        # head room: logits (bf16 + dlogits in place) + the lm_head input gradient, one layer's recomputed activations and gradients
+        budget = 0.85 * free - (4 * M * self.l["vocab"] + 3 * per_layer)
+        keep = int(max(0.0, budget) // max(per_layer + 2 * M * self.l["d"], 1))
+        return max(0, L - keep)
+
+    def _layer_forward(self, i, x, g):
+        """One decoder layer (modeling_llama.py:852-911) on token rows x -> (x_out, the activations backward needs)."""
+        d, F, H = self.l["d"], self.l["ffn"], self.l["heads"]
+        hd, Hkv, kvd = self.hd, self.Hkv, self.kvd
+        B, S, s_pad, lens, cu, pos, cs = g["B"], g["S"], g["s_pad"], g["lens"], g["cu"], g["pos"], g["cs"]
+        lv = self._layer_views(i)
+        h1, rstd1 = ops.rmsnorm_fwd(x, lv["ln1"], self.eps)
+        sv = {}
+        if self.lora:
+            qkv = self._lora_linear(h1, lv["qkv"], i, self._MODS_QKV(d), sv, bias=lv.get("bqkv"))   # frozen q/k/v biases (Qwen2)
+            ops.rope_inplace(qkv, cs, S, H + Hkv, hd, 1, 1, positions=pos)   # q heads then k heads: one run of H + Hkv heads
+        elif not self.fused:
+            qkv = ops.gemm_nt(h1, lv["qkv"], bias=lv.get("bqkv"))
+            ops.rope_inplace(qkv, cs, S, H + Hkv, hd, 1, 1, positions=pos)
+        else:       # q|k|v projection with the rotary embedding in the GEMM epilogue
+            qkv = ops.gemm_rope(h1, lv["qkv"], cs, S, H + Hkv, hd, bias=lv.get("bqkv"), positions=pos)
+        if hd == 128:     # natural-layout kernel: K and V tiles are staged as they lie in memory (no V^T copy)
+            attn, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d:d + kvd], None, B, S, H, hd, s_pad, causal=True, lens=lens, kv_heads=Hkv, cu=cu,
+                                     v=qkv[:, d + kvd:], lse=self._stat_buffer(("lse", i), B, H, s_pad))
+        else:
+            vT = ops.transpose_heads(qkv[:, d + kvd:], B, S, Hkv, hd, s_pad, cu=cu)
+            attn, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d:d + kvd], vT, B, S, H, hd, s_pad, causal=True, lens=lens, kv_heads=Hkv, cu=cu)
+        if self.lora:
+            x_mid = self._lora_linear(attn, lv["o"], i, (("self_attn.o_proj", 0, d),), sv, residual=x)
+        else:
+            x_mid = ops.gemm_nt(attn, lv["o"], residual=x)
+        h2, rstd2 = ops.rmsnorm_fwd(x_mid, lv["ln2"], self.eps)
+        if self.lora:
+            gu = self._lora_linear(h2, lv["gu"], i, (("mlp.gate_proj", 0, F), ("mlp.up_proj", F, 2 * F)), sv)
+            act = ops.swiglu_fwd(gu, F)
+        elif not self.fused:
+            gu = ops.gemm_nt(h2, lv["gu"])
+            act = ops.swiglu_fwd(gu, F)
+        else:       # gate|up projection and silu(gate) * up in one launch
+            gu, act = ops.gemm_swiglu_fwd(h2, lv["gu"], F)
+        if self.lora:
+            x_out = self._lora_linear(act, lv["down"], i, (("mlp.down_proj", 0, d),), sv, residual=x_mid)
+        else:
+            x_out = ops.gemm_nt(act, lv["down"], residual=x_mid)
+        return x_out, dict(x=x, rstd1=rstd1, h1=h1, qkv=qkv, attn=attn, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2, gu=gu, act=act, lora=sv)
+
     def forward(self, input_ids, attention_mask, labels, images, image_sizes=None, want_logits=False, loss_scale=None):
         """One training forward. Returns loss (fp32 device tensor [1], never scaled); keeps the context for backward().
         loss_scale multiplies the GRADIENTS only (default: self.loss_scale; a trainer sets 1 / gradient_accumulation_steps, which is
@@ -571,45 +638,16 @@ class LlavaEngine:
         idx = self._dev(plan["idx"])
         x = ops.gather_rows(idx, d, self.W("model.embed_tokens.weight"), table)
         cs = self.rope_table(S)
+        geom = dict(B=B, S=S, s_pad=s_pad, lens=lens, cu=cu, pos=pos, cs=cs)
+        # activation recompute (the reference's --gradient_checkpointing, train/train.py:164,1505-1513): layers [0, n_re) keep only their
+        # input and re-run their forward inside backward (bit-identical: the kernels are deterministic, LoRA dropout masks regenerable)
+        n_re = self._recompute_layers(M)
         layers = []
         for i in range(L):
-            lv = self._layer_views(i)
-            h1, rstd1 = ops.rmsnorm_fwd(x, lv["ln1"], self.eps)
-            sv = {}
-            if self.lora:
-                qkv = self._lora_linear(h1, lv["qkv"], i, self._MODS_QKV(d), sv, bias=lv.get("bqkv"))   # frozen q/k/v biases (Qwen2)
-                ops.rope_inplace(qkv, cs, S, H + Hkv, hd, 1, 1, positions=pos)   # q heads then k heads: one run of H + Hkv heads
-            elif not self.fused:
-                qkv = ops.gemm_nt(h1, lv["qkv"], bias=lv.get("bqkv"))
-                ops.rope_inplace(qkv, cs, S, H + Hkv, hd, 1, 1, positions=pos)
-            else:       # q|k|v projection with the rotary embedding in the GEMM epilogue
-                qkv = ops.gemm_rope(h1, lv["qkv"], cs, S, H + Hkv, hd, bias=lv.get("bqkv"), positions=pos)
-            if hd == 128:     # natural-layout kernel: K and V tiles are staged as they lie in memory (no V^T copy)
-                attn, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d:d + kvd], None, B, S, H, hd, s_pad, causal=True, lens=lens, kv_heads=Hkv, cu=cu,
-                                         v=qkv[:, d + kvd:], lse=self._stat_buffer(("lse", i), B, H, s_pad))
-            else:
-                vT = ops.transpose_heads(qkv[:, d + kvd:], B, S, Hkv, hd, s_pad, cu=cu)
-                attn, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d:d + kvd], vT, B, S, H, hd, s_pad, causal=True, lens=lens, kv_heads=Hkv, cu=cu)
-            if self.lora:
-                x_mid = self._lora_linear(attn, lv["o"], i, (("self_attn.o_proj", 0, d),), sv, residual=x)
-            else:
-                x_mid = ops.gemm_nt(attn, lv["o"], residual=x)
-            h2, rstd2 = ops.rmsnorm_fwd(x_mid, lv["ln2"], self.eps)
-            if self.lora:
-                gu = self._lora_linear(h2, lv["gu"], i, (("mlp.gate_proj", 0, F), ("mlp.up_proj", F, 2 * F)), sv)
-                act = ops.swiglu_fwd(gu, F)
-            elif not self.fused:
-                gu = ops.gemm_nt(h2, lv["gu"])
-                act = ops.swiglu_fwd(gu, F)
-            else:       # gate|up projection and silu(gate) * up in one launch
-                gu, act = ops.gemm_swiglu_fwd(h2, lv["gu"], F)
-            if self.lora:
-                x_out = self._lora_linear(act, lv["down"], i, (("mlp.down_proj", 0, d),), sv, residual=x_mid)
-            else:
-                x_out = ops.gemm_nt(act, lv["down"], residual=x_mid)
-            layers.append(dict(x=x, rstd1=rstd1, h1=h1, qkv=qkv, attn=attn, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2,
-                               gu=gu, act=act, lora=sv))
+            x_out, acts = self._layer_forward(i, x, geom)
+            layers.append(dict(x=x, lora={}) if i < n_re else acts)
             x = x_out
+        ctx["geom"], ctx["n_recomputed"] = geom, n_re
         hN, rstdN = ops.rmsnorm_fwd(x, self.W("model.norm.weight"), self.eps)
         logits = ops.gemm_nt(hN, self.W("lm_head.weight"))
         tgt = shifted_labels(plan["labels"])
@@ -741,6 +779,8 @@ class LlavaEngine:
             self._bucket_done("model.norm.weight", "model.norm.weight")
         for i in reversed(range(L)):
             a = c["layers"][i]
+            if "h1" not in a:      # activation recompute: this layer kept only its input
+                _, a = self._layer_forward(i, a["x"], c["geom"])
             lv, gv = self._layer_views(i), self._layer_views(i, self.grads)
             sv = a["lora"]
             if self.lora or not self.fused:

@@ -147,14 +147,26 @@ class LlavaLlamaForCausalLM:
                                   train_vision_tower=getattr(config, "unfreeze_mm_vision_tower", False),
                                   lora=getattr(config, "lora", None), freeze_lm=getattr(config, "freeze_lm", False),
                                   train_embed_tokens=getattr(config, "train_embed_tokens", False),
-                                  padding_side=getattr(config, "tokenizer_padding_side", "right"))
+                                  padding_side=getattr(config, "tokenizer_padding_side", "right"),
+                                  recompute=getattr(config, "activation_recompute", False))
         self.model = self.model_class(self.engine, config)
         self.training = True
+        self.is_gradient_checkpointing = bool(self.engine.recompute)
         # a leaf that makes loss require grad so that `.backward()` reaches the engine
         self._anchor = torch.zeros(1, device=self.engine.device, requires_grad=True)
 
     def get_model(self):
         return self.model
+
+    def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None):
+        """HF PreTrainedModel.gradient_checkpointing_enable (what Trainer calls for --gradient_checkpointing, reference
+        train/train.py:1505-1513): every decoder layer keeps only its input and re-runs its forward in backward."""
+        self.engine.recompute = True
+        self.is_gradient_checkpointing = True
+
+    def gradient_checkpointing_disable(self):
+        self.engine.recompute = False
+        self.is_gradient_checkpointing = False
 
     def get_vision_tower(self):
         return self.model.get_vision_tower()

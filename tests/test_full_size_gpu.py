@@ -11,8 +11,9 @@ Reference text followed by the oracle: language_model/modeling_llama.py:1083-118
 train/train.py:140) with the global-norm clip of HF Trainer (max_grad_norm) and the decay / no-decay groups of
 LLaVATrainer.create_optimizer (train/llava_trainer.py:369-418).
 
-Host memory: fp32 parameters + gradients + two AdamW moments of 6.76 B parameters = 108 GB (the GPU box allows ~270 GiB).  If the host
-offers less than 150 GB the test runs 8 full-width layers + head instead and says so in its record (RV_FULLSIZE_LAYERS overrides).
+Host memory: working weights + gradients + fp32 masters + two AdamW moments of 6.76 B parameters = 135 GB (the GPU box allows ~270 GiB).
+If the host offers less than 180 GB the test runs 8 full-width layers + head instead and says so in its record (RV_FULLSIZE_LAYERS
+overrides).
 """
 import copy
 import json
@@ -56,7 +57,7 @@ def test_config2_full_size_forward_backward_two_adamw_steps():
     from conftest import ROOT, record_measurement
     t_start = time.time()
     want = os.environ.get("RV_FULLSIZE_LAYERS")
-    layers = int(want) if want else (32 if _avail_gb() >= 150 else 8)
+    layers = int(want) if want else (32 if _avail_gb() >= 180 else 8)
     geo = copy.deepcopy(GEOMETRIES["llava15_7b"])
     geo["lm"]["layers"] = layers
     V = geo["lm"]["vocab"]
@@ -81,6 +82,11 @@ def test_config2_full_size_forward_backward_two_adamw_steps():
         P[k].requires_grad_(True)
     a = (ids, mask, labels, images)
     rec = dict(layers=layers, trainable_params=n_params, host_threads=torch.get_num_threads())
+
+    def dump():
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "full_size_parity.json"), "w") as f:
+            json.dump(rec, f, indent=1)
 
     def hip_step():
         loss = float(eng.forward(ids.numpy(), mask.numpy(), labels.numpy(), images, want_logits=True))
@@ -111,22 +117,31 @@ def test_config2_full_size_forward_backward_two_adamw_steps():
             per_kind[kind] = max(per_kind.get(kind, 0.0), rel)
             if rel > worst:
                 worst, worst_name = rel, k
-            assert rn > 0 and rel < GRAD_REL_L2, (tag, k, rel, rn)
+            if not (rn > 0 and rel < GRAD_REL_L2):
+                rec[tag + "_failed"] = dict(tensor=k, rel_l2=rel, ref_norm=rn, per_kind_worst_rel_l2=per_kind)
+                dump()
+                raise AssertionError((tag, k, rel, rn, rec))
         gn_h, gn_r = math.sqrt(sq_h), math.sqrt(sq_r)
         rec[tag] = dict(worst_rel_l2=worst, worst_tensor=worst_name, per_kind_worst_rel_l2=per_kind, grad_norm_hip=gn_h, grad_norm_fp32=gn_r)
+        dump()
         assert abs(gn_h - gn_r) <= GRAD_NORM_REL * gn_r, (tag, gn_h, gn_r)
         return gn_r
 
-    M, Vv = {}, {}
+    M, Vv, MASTER = {}, {}, {}
 
     def oracle_adamw(step, total_norm):
+        """fp32 AdamW on fp32 master weights; the weights the next forward multiplies with are the masters rounded to bf16 -- the
+        storage scheme under test (the reference's run: bf16 model, fp32 optimizer state, zero3.json `bf16.enabled`).  Without the
+        rounding the two models would differ after one update by the weights' bf16 rounding noise (~0.5 ulp = 6e-5 at |w| = 0.02, the
+        size of the update itself), which is not an error of the kernels."""
         coef = min(1.0, clip / (total_norm + 1e-6))           # torch.nn.utils.clip_grad_norm_
         with torch.no_grad():
             for k in names:
                 p = P[k]
                 if k not in M:
-                    M[k], Vv[k] = torch.zeros_like(p), torch.zeros_like(p)
-                O.adamw_step(p, p.grad * coef, M[k], Vv[k], step, lr, b1, b2, eps, 0.0 if _no_decay(k, p.shape) else wd)
+                    M[k], Vv[k], MASTER[k] = torch.zeros_like(p), torch.zeros_like(p), p.detach().clone()
+                O.adamw_step(MASTER[k], p.grad * coef, M[k], Vv[k], step, lr, b1, b2, eps, 0.0 if _no_decay(k, p.shape) else wd)
+                p.copy_(MASTER[k].to(torch.bfloat16).float())
 
     # ---- step 1: forward (vs fp32 oracle and vs the bf16-emulating oracle), backward, optimizer
     loss1, logits, pm = hip_step()
@@ -141,6 +156,7 @@ def test_config2_full_size_forward_backward_two_adamw_steps():
     rec.update(loss_hip=loss1, loss_fp32=rl1, loss_emu=float(le), hip_vs_fp32_inf=relinf(logits, rlog), hip_vs_fp32_l2=rel2(logits, rlog),
                emu_vs_fp32_inf=relinf(lge, rlog), emu_vs_fp32_l2=rel2(lge, rlog), hip_vs_emu_inf=relinf(logits, lge), hip_vs_emu_l2=rel2(logits, lge))
     del lge, rlog
+    dump()
     assert abs(loss1 - rl1) <= LOSS_TOL, rec
     assert abs(loss1 - float(le)) <= LOSS_TOL, rec
     # the same three inequalities as test_bf16_emulated_parity: as close to fp32 as an ideal bf16 implementation of the same store points
@@ -166,7 +182,7 @@ def test_config2_full_size_forward_backward_two_adamw_steps():
     worst_mean, worst_bad, worst_ulp = (0.0, None), (0.0, None), 0
     for k in names:
         off, n = eng.lm.offsets[k]
-        ref = P[k].detach().to("cuda:0").view(-1)
+        ref = MASTER[k].to("cuda:0").view(-1)
         mas = eng.master[off:off + n]
         par = eng.lm.flat[off:off + n]
         assert torch.equal(par, mas.to(torch.bfloat16)), k                      # the bf16 parameters ARE the rounded master copy
@@ -185,7 +201,5 @@ def test_config2_full_size_forward_backward_two_adamw_steps():
     rec.update(update_worst_mean_over_lr=worst_mean, update_worst_frac_gt_half_lr=worst_bad, worst_bf16_ulp=worst_ulp,
                seconds=time.time() - t_start, lr=lr, weight_decay=wd, max_grad_norm=clip)
     record_measurement("config2_full_size", **rec)
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "full_size_parity.json"), "w") as f:
-        json.dump(rec, f, indent=1)
+    dump()
     print(json.dumps(rec))

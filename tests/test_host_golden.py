@@ -303,3 +303,53 @@ def test_saved_checkpoint_is_consumable_by_the_converter(golden_dir, tmp_path):
     got = check_checkpoint_dir(str(tmp_path / "b"))
     want = _json.load(open(os.path.join(golden_dir, "host_convert_keys.json")))["mapping"]
     assert sorted(got) == sorted(want.values())
+
+
+def test_instruction_generators_replay_the_reference(golden_dir):
+    """radvlm_amd.data.create_instructions against outputs of the reference's own generators (radvlm/data/create_instructions.py:9-26,
+    :120-529; fixture from tests/golden/make_golden_instructions.py): same text for the same `random` seed, and the generator left in
+    the same state (the next `random.random()` agrees), i.e. the draws happen in the reference's order."""
+    import random
+    from radvlm_amd.data import create_instructions as ci
+    G = json.load(open(os.path.join(golden_dir, "instruction_generators.json"), encoding="utf-8"))
+    n = 0
+    for fn, recs in G.items():
+        if fn == "grouped_length_mismatch_error":
+            continue
+        for r in recs:
+            random.seed(r["seed"])
+            got = getattr(ci, fn)(*r["args"], **r["kwargs"])
+            assert got == r["result"], (fn, r["args"], r["seed"], got, r["result"])
+            assert random.random() == r["next_random"], (fn, r["seed"])
+            n += 1
+    assert n > 300
+    with pytest.raises(ValueError, match=G["grouped_length_mismatch_error"][:20]):
+        ci.generate_instruction_abnormalities_grouped([[0, 0, 1, 1]], ["a", "b"])
+    with pytest.raises(IndexError):
+        ci.format_boxes([])
+
+
+def test_dropin_radvlm_package_extends_instead_of_shadowing(tmp_path):
+    """`dropin/radvlm` must not hide the reference's own `radvlm` package (INTEGRATION.md section 1 puts dropin/ first on PYTHONPATH):
+    it is a namespace extension -- submodules this build does not restate (radvlm.data.datasets, radvlm.evaluation, ...) still resolve
+    to whatever `radvlm` tree follows on the path.  Checked in a child process against a stand-in tree."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    other = tmp_path / "site"
+    (other / "radvlm" / "data").mkdir(parents=True)
+    (other / "radvlm" / "evaluation").mkdir()
+    (other / "radvlm" / "__init__.py").write_text("raise RuntimeError('the stand-in package __init__ must not be needed')\n")
+    (other / "radvlm" / "data" / "__init__.py").write_text("")
+    (other / "radvlm" / "data" / "datasets.py").write_text("MARK = 'datasets of the other tree'\n")
+    (other / "radvlm" / "evaluation" / "__init__.py").write_text("MARK = 'evaluation of the other tree'\n")
+    code = ("import radvlm.data.datasets as d, radvlm.evaluation as e, radvlm.data.create_instructions as c, radvlm.data as rd;"
+            "from radvlm import DATA_DIR;"
+            "print(d.MARK, '|', e.MARK, '|', c.__name__, '|', callable(rd.create_json_cell_llava), '|', DATA_DIR)")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, os.path.join(root, "dropin"), str(other)]), DATA_DIR="/data/cxr")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert p.returncode == 0, p.stderr[-800:]
+    assert p.stdout.strip() == "datasets of the other tree | evaluation of the other tree | radvlm.data.create_instructions | True | /data/cxr"
+    env.pop("DATA_DIR")
+    p = subprocess.run([sys.executable, "-c", "from radvlm import DATA_DIR"], capture_output=True, text=True, env=env)
+    assert p.returncode != 0 and "DATA_DIR" in p.stderr          # same error behaviour as the reference's radvlm/__init__.py:5-7

@@ -260,3 +260,51 @@ def test_bf16_emulation_reduces_to_oracle(golden_dir, name, geo_name):
     l2, lg2, _ = E.llava_forward(P, geo, *a, emulate=True)
     floor = float((lg2[m] - lg0[m]).abs().max() / lg0[m].abs().max())
     assert 1e-3 < floor < 3e-2 and abs(float(l2) - float(l0)) < 1e-2, (floor, float(l2), float(l0))
+
+
+@pytest.mark.parametrize("kvh,bias", [(4, False), (2, True)])
+def test_bf16_emulation_backward_reduces_to_autograd(kvh, bias):
+    """oracle/bf16_emulation.py::decoder_layer_backward is the hand-written derivative of the decoder layer with the HIP backward's
+    bf16 store points.  Pin: with the rounding switched off it must equal torch autograd of the (reference-pinned) oracle layer
+    -- input gradient, every weight gradient, the q/k/v bias gradient -- to 1e-5, with and without grouped-query heads / biases
+    and with a padded (shorter) sample in the batch."""
+    from oracle import bf16_emulation as E
+    l = dict(d=64, heads=4, kv_heads=kvh, ffn=96, layers=1, vocab=8, qkv_bias=bias)
+    pre = "model.layers.0."
+    g = torch.Generator().manual_seed(3)
+    hd, kvd = 16, 16 * kvh
+    shapes = {"self_attn.q_proj.weight": (64, 64), "self_attn.k_proj.weight": (kvd, 64), "self_attn.v_proj.weight": (kvd, 64),
+              "self_attn.o_proj.weight": (64, 64), "mlp.gate_proj.weight": (96, 64), "mlp.up_proj.weight": (96, 64),
+              "mlp.down_proj.weight": (64, 96), "input_layernorm.weight": (64,), "post_attention_layernorm.weight": (64,)}
+    if bias:
+        shapes.update({"self_attn.q_proj.bias": (64,), "self_attn.k_proj.bias": (kvd,), "self_attn.v_proj.bias": (kvd,)})
+    P = {pre + k: (torch.randn(*s, generator=g) * (0.2 if len(s) == 2 else 1.0)).requires_grad_(True) for k, s in shapes.items()}
+    B, S, lens = 2, 24, [24, 17]
+    x = torch.randn(B, S, 64, generator=g).requires_grad_(True)
+    dy = torch.randn(B, S, 64, generator=g)
+    dy[1, 17:] = 0.0                                          # padding rows carry no gradient
+    cos, sin = O.rope_cos_sin(S, hd)
+    y = O.decoder_layer(x, P, pre, 4, lens, cos, sin, 1e-5, kvh)
+    y.backward(dy)
+    Pd = {k: v.detach() for k, v in P.items()}
+    E.TRACE = {}
+    try:
+        inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, dtype=torch.int64).float() / hd))
+        fr = torch.outer(torch.arange(S, dtype=torch.float32), inv)
+        y2 = E.decoder_layer(x.detach(), Pd, pre, l, lens, fr.cos(), fr.sin(), 1e-5, E.identity)
+        T = E.TRACE
+    finally:
+        E.TRACE = None
+    assert float((y2 - y.detach()).abs().max()) < 1e-5
+    out = E.decoder_layer_backward(T, Pd, pre, l, lens, dy, E.identity)
+    close = lambda a, b: float((a - b).abs().max() / b.abs().max()) < 1e-5
+    m = torch.zeros(B, S, dtype=torch.bool)
+    m[0], m[1, :17] = True, True
+    assert close(out["dx_in"][m], x.grad[m])
+    assert close(out["gW_down"], P[pre + "mlp.down_proj.weight"].grad)
+    assert close(out["gW_gu"], torch.cat((P[pre + "mlp.gate_proj.weight"].grad, P[pre + "mlp.up_proj.weight"].grad), 0))
+    assert close(out["gW_o"], P[pre + "self_attn.o_proj.weight"].grad)
+    assert close(out["gW_qkv"], torch.cat([P[pre + f"self_attn.{n}_proj.weight"].grad for n in "qkv"], 0))
+    assert close(out["g_ln1"], P[pre + "input_layernorm.weight"].grad) and close(out["g_ln2"], P[pre + "post_attention_layernorm.weight"].grad)
+    if bias:
+        assert close(out["g_bqkv"], torch.cat([P[pre + f"self_attn.{n}_proj.bias"].grad for n in "qkv"], 0))

@@ -289,3 +289,105 @@ def test_device_image_normalisation_gives_the_same_training_run(tmp_path):
         assert [r["loss"] for r in a["log_history"]] == [r["loss"] for r in b["log_history"]]
     finally:
         conv_lib.default_conversation = conv_lib.conv_templates["v1"]
+
+
+def _toy_batch(golden_dir, name="toy_e2e"):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    n = len([k for k in g.files if k.startswith("image") and k[5:].isdigit()])
+    return g, [torch.from_numpy(g[f"image{i}"]) for i in range(n)]
+
+
+@pytest.mark.parametrize("geo_name,golden,kw", [("toy", "toy_e2e", {}), ("toy_qwen", "toy_qwen_e2e", {}),
+                                                ("toy", "toy_e2e", {"lora": dict(r=8, alpha=16, dropout=0.1)})])
+def test_activation_recompute_is_bit_identical(golden_dir, geo_name, golden, kw):
+    """--gradient_checkpointing (reference train/train.py:164,1505-1513; modeling_llama.py:1139-1149): a layer that keeps only its input
+    and re-runs its forward inside backward must leave bit-identical gradients (deterministic kernels; LoRA dropout masks are
+    regenerated from the step's seed), whether all layers recompute or only the first one."""
+    _need_gpu()
+    from radvlm_amd.engine import LlavaEngine
+    g, images = _toy_batch(golden_dir, golden)
+    grads, losses = [], []
+    for rc in (False, True, 1):
+        eng = LlavaEngine(GEOMETRIES[geo_name], device="cuda:0", init="portable", seed=0, recompute=bool(rc), **kw)
+        if rc == 1:        # partial: only layer 0 recomputes
+            eng._recompute_layers = lambda M: 1
+        if kw.get("lora"):
+            for n in eng.lm.names():      # peft zero-initialises lora_B: give it values so that the adapter path carries gradient
+                if n.endswith("lora_B.weight"):
+                    eng.lm.view(n).copy_(torch.randn(eng.lm.shapes[n], generator=torch.Generator().manual_seed(len(n))).to("cuda:0") * 0.05)
+        loss = eng.forward(g["input_ids"], g["attention_mask"], g["labels"], images)
+        if rc:
+            assert eng.ctx["n_recomputed"] == (eng.l["layers"] if rc is True else 1)
+            assert all(set(a) == {"x", "lora"} for a in eng.ctx["layers"][:eng.ctx["n_recomputed"]])
+        eng.backward()
+        torch.cuda.synchronize()
+        grads.append(eng.grads.clone())
+        losses.append(float(loss))
+    assert losses[0] == losses[1] == losses[2]
+    assert float(grads[0].float().abs().max()) > 0
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+
+
+def test_auto_recompute_keeps_activations_when_they_fit(golden_dir):
+    """recompute="auto" (what --gradient_checkpointing True selects): no layer recomputes while the batch's activations fit in free HBM,
+    and the count grows with the token rows of a (hypothetical) batch."""
+    _need_gpu()
+    from radvlm_amd.engine import LlavaEngine
+    eng = LlavaEngine(GEOMETRIES["toy"], device="cuda:0", init="portable", seed=0, recompute="auto")
+    assert eng._recompute_layers(96) == 0
+    free, _ = torch.cuda.mem_get_info()
+    rows_too_many = int(free // eng.activation_bytes_per_row())       # one layer alone would fill the device
+    assert eng._recompute_layers(rows_too_many) == eng.l["layers"]
+    # 7B widths: 32 pairs x 704 tokens keep ~95 GB of activations (DESIGN section 3)
+    big = LlavaEngine.__new__(LlavaEngine)
+    big.l, big.kvd = GEOMETRIES["llava15_7b"]["lm"], 4096
+    assert 90e9 < 32 * 704 * 32 * big.activation_bytes_per_row() < 100e9
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_stale_softmax_statistics_are_masked(golden_dir, packed):
+    """The lse / delta buffers are cached by padded shape and only the valid rows are rewritten: a batch with the same (B, s_pad) but
+    shorter samples sees stale values in rows >= len.  They must not reach any gradient (the kernels mask those rows)."""
+    _need_gpu()
+    from radvlm_amd.engine import LlavaEngine
+    g, images = _toy_batch(golden_dir)
+    ids, lab = g["input_ids"].copy(), g["labels"].copy()
+    am_full = np.ones_like(g["attention_mask"])
+    am_short = am_full.copy()
+    am_short[:, -9:] = False            # same padded shape, every sample 9 tokens shorter
+    lab_short = np.where(am_short, lab, -100)
+
+    def run(eng, am, lb):
+        eng.forward(ids, am, lb, images)
+        eng.backward()
+        torch.cuda.synchronize()
+        eng.zero_grad()
+        return eng.grads.clone()
+    a = LlavaEngine(GEOMETRIES["toy"], device="cuda:0", init="portable", seed=0, packed=packed)
+    run(a, am_full, lab)                                  # fills lse / delta for all rows
+    # plant large (finite: stale values are old statistics) numbers where a later, shorter batch must not look
+    assert a._stats
+    for k, buf in a._stats.items():
+        buf[..., -9:] = 1e30
+    ga = run(a, am_short, lab_short)
+    b = LlavaEngine(GEOMETRIES["toy"], device="cuda:0", init="portable", seed=0, packed=packed)
+    gb = run(b, am_short, lab_short)
+    assert torch.isfinite(ga.float()).all() and torch.equal(ga, gb)
+
+
+def test_images_already_on_the_device(golden_dir):
+    """HF Trainer._prepare_inputs moves every tensor of the batch to the device before model(**batch): device-resident images (and ids)
+    must be accepted and give the same loss as host tensors."""
+    _need_gpu()
+    from radvlm_amd.llava.model import LlavaConfig, LlavaLlamaForCausalLM
+    g, images = _toy_batch(golden_dir)
+    model = LlavaLlamaForCausalLM(LlavaConfig(geometry=GEOMETRIES["toy"]), device="cuda:0")
+    t = lambda a: torch.from_numpy(np.asarray(a))
+    host = model(input_ids=t(g["input_ids"]), attention_mask=t(g["attention_mask"]), labels=t(g["labels"]), images=images)
+    l0 = float(host.loss)
+    model.engine.ctx = None
+    dev = model(input_ids=t(g["input_ids"]).cuda(), attention_mask=t(g["attention_mask"]).cuda(), labels=t(g["labels"]).cuda(),
+                images=torch.stack(images).cuda())
+    assert float(dev.loss) == l0
+    dev.loss.backward()
+    torch.cuda.synchronize()
