@@ -354,7 +354,7 @@ def test_stale_softmax_statistics_are_masked(golden_dir, packed):
     ids, lab = g["input_ids"].copy(), g["labels"].copy()
     am_full = np.ones_like(g["attention_mask"])
     am_short = am_full.copy()
-    am_short[:, -9:] = False            # same padded shape, every sample 9 tokens shorter
+    am_short[-1, -9:] = False           # same padded shape (B, s_pad), the last sample 9 tokens shorter
     lab_short = np.where(am_short, lab, -100)
 
     def run(eng, am, lb):
@@ -368,7 +368,7 @@ def test_stale_softmax_statistics_are_masked(golden_dir, packed):
     # plant large (finite: stale values are old statistics) numbers where a later, shorter batch must not look
     assert a._stats
     for k, buf in a._stats.items():
-        buf[..., -9:] = 1e30
+        buf[-1, :, :] = torch.where(buf[-1] != 0, torch.full_like(buf[-1], 1e30), buf[-1])     # the last sample's rows: all stale now
     ga = run(a, am_short, lab_short)
     b = LlavaEngine(GEOMETRIES["toy"], device="cuda:0", init="portable", seed=0, packed=packed)
     gb = run(b, am_short, lab_short)
