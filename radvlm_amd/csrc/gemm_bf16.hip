@@ -42,6 +42,7 @@ struct GemmParams {
     const float* rope_cs; const int* rope_pos; int rope_S, rope_cols, rope_hd;
     int F; bf16* C2; long ldc2; const bf16* G; long ldg;
     unsigned bytesA, bytesB;     // BUF kernels: extent of each operand = its buffer resource's num_records
+    unsigned bytesA2, bytesB2;   // BUF + MODE 1: the second operand pair's extents
 };
 enum { EPI_NONE = 0, EPI_ROPE = 1, EPI_SWIGLU_FWD = 2, EPI_SWIGLU_BWD = 3 };
 
@@ -796,7 +797,7 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
 #ifdef RV_NO_PERSIST
     constexpr bool PERSIST = false;
 #else
-    constexpr bool PERSIST = (MODE == 0 || MODE == 3) && BUF;
+    constexpr bool PERSIST = (MODE == 0 || MODE == 1 || MODE == 3) && BUF;
 #endif
     int vtile = blockIdx.x, kslice = 0;
     bool sliced = MODE == 2;
@@ -842,17 +843,45 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
             else plB[h] = plan_half<TB, true, 0>(P.ldb, n0 + h * 128, P.N, wid, lane, h, 0, P.bytesB);
         }
     };
+    // MODE 1 (second operand pair, K-tiles nt1 .. nt-1): its own resources and per-lane offsets (other leading dimensions); which pair a
+    // staging piece belongs to is a compile-time tag in the steady-state loops (PAIR 0 / 1) and a run-time test only in the prologue
+    __amdgpu_buffer_rsrc_t rsA2, rsB2;
+    HalfPlan plA2[2], plB2[2];
+    if constexpr (BUF && MODE == 1) {
+        rsA2 = __builtin_amdgcn_make_buffer_rsrc((void*)P.A2, 0, P.bytesA2, 0x00020000);
+        rsB2 = __builtin_amdgcn_make_buffer_rsrc((void*)P.B2, 0, P.bytesB2, 0x00020000);
+    }
+    auto make_plans2 = [&]() {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            plA2[h] = plan_half<TA, false, 0>(P.lda2, m0 + h * 128, P.M, wid, lane, h, 0, P.bytesA2);
+            plB2[h] = plan_half<TB, true, 0>(P.ldb2, n0 + h * 128, P.N, wid, lane, h, 0, P.bytesB2);
+        }
+    };
     if constexpr (BUF) make_plans();
+    if constexpr (BUF && MODE == 1) make_plans2();
     const int kstepA = TA ? (int)(P.lda * BK * 2) : BK * 2, kstepB = TB ? (int)(P.ldb * BK * 2) : BK * 2;    // bytes per K-tile
-    auto stageA = [&](int t, int slot, int h) {
+    const int kstepA2 = TA ? (int)(P.lda2 * BK * 2) : BK * 2, kstepB2 = TB ? (int)(P.ldb2 * BK * 2) : BK * 2;
+    // PAIR: 0 = first operand pair, 1 = second, 2 = decide at run time (t >= nt1); only MODE 1 has a second pair
+    auto stageA = [&](int t, int slot, int h, auto pair_tag) {
+        constexpr int PAIR = decltype(pair_tag)::value;
         char* dst = smem + (slot * 2 + h) * HALF_BYTES;
-        if constexpr (BUF) { stage_half_buf(rsA, plA[h], (t0 + t) * kstepA, dst, wid); return; }
+        if constexpr (BUF) {
+            if (MODE == 1 && (PAIR == 1 || (PAIR == 2 && t >= nt1))) stage_half_buf(rsA2, plA2[h], (t - nt1) * kstepA2, dst, wid);
+            else stage_half_buf(rsA, plA[h], (t0 + t) * kstepA, dst, wid);
+            return;
+        }
         if (MODE == 1 && t >= nt1) stage_half<TA>(P.A2, P.lda2, m0 + h * 128, P.M, (t - nt1) * BK, P.K2, P.zeros, dst, wid, lane);
         else stage_half<TA>(P.A, P.lda, m0 + h * 128, P.M, (t0 + t) * BK, P.K, P.zeros, dst, wid, lane);
     };
-    auto stageB = [&](int t, int h) {
+    auto stageB = [&](int t, int h, auto pair_tag) {
+        constexpr int PAIR = decltype(pair_tag)::value;
         char* dst = smem + B_RING_OFF + ((t & 1) * 2 + h) * HALF_BYTES;
-        if constexpr (BUF) { stage_half_buf(rsB, plB[h], (t0 + t) * kstepB, dst, wid); return; }
+        if constexpr (BUF) {
+            if (MODE == 1 && (PAIR == 1 || (PAIR == 2 && t >= nt1))) stage_half_buf(rsB2, plB2[h], (t - nt1) * kstepB2, dst, wid);
+            else stage_half_buf(rsB, plB[h], (t0 + t) * kstepB, dst, wid);
+            return;
+        }
         if (MODE == 1 && t >= nt1) stage_half<TB, true>(P.B2, P.ldb2, n0 + h * 128, P.N, (t - nt1) * BK, P.K2, P.zeros, dst, wid, lane);
         else if (EPI == EPI_ROPE) {
             if (P.rope_hd == 128) stage_half<TB, true, 1>(P.B, P.ldb, n0 + h * 128, P.N, (t0 + t) * BK, P.K, P.zeros, dst, wid, lane);
@@ -862,10 +891,13 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
     };
 
     // prologue: tiles 0 and 1 (tile 1 stays in flight)
-    stageA(0, 0, 0); stageA(0, 0, 1); stageB(0, 0); stageB(0, 1);
+    constexpr std::integral_constant<int, 0> P0{};
+    constexpr std::integral_constant<int, 1> P1{};
+    constexpr std::integral_constant<int, 2> PR{};
+    stageA(0, 0, 0, P0); stageA(0, 0, 1, P0); stageB(0, 0, P0); stageB(0, 1, P0);
     int vt0 = blockIdx.x;
     do {    // one trip unless PERSIST
-    if (nt > 1) { stageA(1, 1, 0); stageA(1, 1, 1); stageB(1, 0); stageB(1, 1); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    if (nt > 1) { stageA(1, 1, 0, PR); stageA(1, 1, 1, PR); stageB(1, 0, PR); stageB(1, 1, PR); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     RV_STAMP(1);
@@ -881,17 +913,17 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
     long long dbg[4] = {0, 0, 0, 0};   // diagnostic build only (RV_STAMPS): parked-cycle accumulators; dead code otherwise
     // One K-tile step.  STAGE = this step issues the staging of tile t + 2 (all steps but the last two): the steady-state loop is
     // straight-line code without the four `t + 2 < nt` branches that used to cut it into basic blocks (hipcc schedules within one).
-    auto step = [&](int t, auto stage_tag) {
+    auto step = [&](int t, auto stage_tag, auto pair_tag) {
         constexpr int STAGE = decltype(stage_tag)::value;      // 1 = stage tile t + 2, 0 = do not, 2 = decide at run time (t + 2 < nt)
         const char* At = smem + (aslot * 2 + wr) * HALF_BYTES;
         const char* Bt = smem + B_RING_OFF + ((t & 1) * 2 + (wc >> 1)) * HALF_BYTES;
         const int aslot2 = aslot == 0 ? 2 : aslot - 1;   // (t + 2) % 3: the slot tile t-1 just vacated
         const int brow0 = (wc & 1) * 64;
         ktile_256<TA, TB>(acc, At, Bt, brow0, lane,
-                          [&]() { if (STAGE == 1 || (STAGE == 2 && t + 2 < nt)) stageA(t + 2, aslot2, 0); },
-                          [&]() { if (STAGE == 1 || (STAGE == 2 && t + 2 < nt)) stageA(t + 2, aslot2, 1); },
-                          [&]() { if (STAGE == 1 || (STAGE == 2 && t + 2 < nt)) stageB(t + 2, 0); },
-                          [&]() { if (STAGE == 1 || (STAGE == 2 && t + 2 < nt)) stageB(t + 2, 1); }, dbg);
+                          [&]() { if (STAGE == 1 || (STAGE == 2 && t + 2 < nt)) stageA(t + 2, aslot2, 0, pair_tag); },
+                          [&]() { if (STAGE == 1 || (STAGE == 2 && t + 2 < nt)) stageA(t + 2, aslot2, 1, pair_tag); },
+                          [&]() { if (STAGE == 1 || (STAGE == 2 && t + 2 < nt)) stageB(t + 2, 0, pair_tag); },
+                          [&]() { if (STAGE == 1 || (STAGE == 2 && t + 2 < nt)) stageB(t + 2, 1, pair_tag); }, dbg);
         // tile t+1 (issued during tile t-1) must have landed; the 8 loads of tile t+2 stay in flight
         RV_ACC_BEGIN();
         if (STAGE == 1 || (STAGE == 2 && t + 2 < nt)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -902,14 +934,21 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
         BAR_LGKM();   // also: every wave's A reads of tile t are complete -> the A halves of this slot may be restaged
         RV_ACC_END(2);
     };
-    if constexpr (MODE == 1 || MODE == 2) {
-        // the two-operand-pair and split-K forms keep the single loop with run-time staging decisions: two copies of the K-tile
-        // step do not fit their register budget (they are r-wide LoRA products and small outputs, not the step's bulk)
-        for (int t = 0; t < nt; ++t) step(t, std::integral_constant<int, 2>{});
+    if constexpr (MODE == 2 || (MODE == 1 && !BUF)) {
+        // the split-K form and the flat-addressed two-pair form keep the single loop with run-time staging decisions (small outputs /
+        // shapes the buffer-addressed kernel does not take: not the step's bulk)
+        for (int t = 0; t < nt; ++t) step(t, std::integral_constant<int, 2>{}, PR);
+    } else if constexpr (MODE == 1) {
+        // fused second operand pair (LoRA: [x | t] [W | B]^T), buffer-addressed: the steady-state loop stages from the first pair, a
+        // short second loop from the adapter pair (one K-tile at r = 64), the last two steps stage nothing -- all branch-free
+        int t = 0;
+        for (; t + 2 < nt1; ++t) step(t, std::integral_constant<int, 1>{}, P0);
+        for (; t + 2 < nt; ++t) step(t, std::integral_constant<int, 1>{}, P1);
+        for (; t < nt; ++t) step(t, std::integral_constant<int, 0>{}, P0);
     } else {
         int t = 0;
-        for (; t + 2 < nt; ++t) step(t, std::integral_constant<int, 1>{});
-        for (; t < nt; ++t) step(t, std::integral_constant<int, 0>{});
+        for (; t + 2 < nt; ++t) step(t, std::integral_constant<int, 1>{}, P0);
+        for (; t < nt; ++t) step(t, std::integral_constant<int, 0>{}, P0);
     }
 #ifdef RV_STAMPS
     if (MODE == 0 && P.ws && lane == 0) {   // per wave: [mid barrier, end vmcnt, end barrier] parked cycles of the whole K loop
@@ -938,7 +977,11 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
     if constexpr (PERSIST) {
         vt0 += MODE == 3 ? P.pgrid : (int)gridDim.x;
         more = !sliced && vt0 < (MODE == 3 ? P.n_full : nwg);
-        if (more) { coords(vt0); make_plans(); stageA(0, 0, 0); stageA(0, 0, 1); stageB(0, 0); stageB(0, 1); }
+        if (more) {
+            coords(vt0); make_plans();
+            if constexpr (MODE == 1) make_plans2();
+            stageA(0, 0, 0, P0); stageA(0, 0, 1, P0); stageB(0, 0, P0); stageB(0, 1, P0);
+        }
     }
     if (EPI != EPI_NONE) epilogue_fused<EPI>(acc, P, m0e, tne, wr, wc, lane);
     else epilogue_256<MODE == 3 ? 0 : MODE>(acc, P, m0e, n0e, wr, wc, lane, kslice);
@@ -1056,6 +1099,13 @@ static bool buf_extents(GemmParams& P, int trans_a, int trans_b) {
     P.bytesA = (unsigned)ea; P.bytesB = (unsigned)eb;
     return true;
 }
+static bool buf_extents2(GemmParams& P, int trans_a, int trans_b) {
+    if (P.K2 % BK) return false;
+    const long ea = (trans_a ? (long)P.K2 : (long)P.M) * P.lda2 * 2, eb = (trans_b ? (long)P.K2 : (long)P.N) * P.ldb2 * 2;
+    if (ea >= (1L << 31) || eb >= (1L << 31)) return false;
+    P.bytesA2 = (unsigned)ea; P.bytesB2 = (unsigned)eb;
+    return true;
+}
 template <bool TA, bool TB, int MODE, bool BUF = false>
 static void launch256m(const GemmParams& P, hipStream_t st) {
     static bool set = false;
@@ -1067,7 +1117,7 @@ static void launch256m(const GemmParams& P, hipStream_t st) {
     Q.pgrid = MODE == 3 ? P.n_full : blocks;
 #ifndef RV_NO_PERSIST
     // persistent form: one block per CU walks the whole tiles (MODE 3: + the K-slice blocks of the tail tiles behind them)
-    if (g_persist && BUF && MODE == 0 && blocks > cu_budget()) { grid = cu_budget(); Q.pgrid = grid; }
+    if (g_persist && BUF && (MODE == 0 || MODE == 1) && blocks > cu_budget()) { grid = cu_budget(); Q.pgrid = grid; }
     if (g_persist && BUF && MODE == 3 && P.n_full > cu_budget()) { Q.pgrid = cu_budget(); grid = Q.pgrid + (nwg - P.n_full) * P.splits; }
 #endif
     hipLaunchKernelGGL((gemm_kernel_256<TA, TB, MODE, EPI_NONE, BUF>), dim3(grid), dim3(512), LDS_BYTES2, st, Q);
@@ -1079,7 +1129,7 @@ static void launch256m(const GemmParams& P, hipStream_t st) {
 }
 template <bool TA, bool TB>
 static void launch256(GemmParams& P, int mode, hipStream_t st) {
-    if (mode == 1) launch256m<TA, TB, 1>(P, st);
+    if (mode == 1) { if (buf_extents(P, TA, TB) && buf_extents2(P, TA, TB)) launch256m<TA, TB, 1, true>(P, st); else launch256m<TA, TB, 1>(P, st); }
     else if (mode == 2) launch256m<TA, TB, 2>(P, st);
     else if (buf_extents(P, TA, TB)) { if (mode == 3) launch256m<TA, TB, 3, true>(P, st); else launch256m<TA, TB, 0, true>(P, st); }
     else if (mode == 3) launch256m<TA, TB, 3>(P, st);

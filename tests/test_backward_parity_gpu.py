@@ -6,7 +6,8 @@ input gradients (`rv_gemm_bf16` row x contraction-major), the SwiGLU backward fu
 (`rv_gemm_swiglu_bwd_bf16`) and its unfused sequence, `rv_rmsnorm_bwd`, `rv_attn_bwd_nat` (dQ, dK, dV with the rotary adjoint) -- is run on
 the inputs the emulated backward chain (oracle/bf16_emulation.py::decoder_layer_backward, pinned to torch autograd of the reference-pinned
 oracle by tests/test_oracle_golden.py) feeds it, and must reproduce that op's emulated output:
-  bf16 outputs : at most 1e-3 of the elements differ, each by one ulp (an fp32 sum of a different order straddling a rounding boundary);
+  bf16 outputs : at most 1e-3 of the elements differ, each by one ulp (an fp32 sum of a different order straddling a rounding boundary;
+                 elements smaller than 2^-12 of the tensor's largest are measured in the ulp of that floor);
   fp32 weight-gradient sums (GEMM with out_f32) : ||d||_inf / ||ref||_inf <= 1e-5 against a float64 product.
 A 3 % error in any backward kernel fails here (the end-to-end gradient gates cannot see that: bf16 noise through the layers is of that order).
 """
@@ -110,8 +111,12 @@ def test_layer0_backward_ops_on_bf16_exact_inputs(golden_dir, case):
         emu = emu.reshape(-1, emu.shape[-1])
         if not all_rows:
             hip, emu = hip[rows], emu[rows]
-        dif = (_mono(hip) - _mono(rnd(emu))).abs()
-        res[name] = dict(mismatch_frac=float((dif != 0).float().mean()), max_ulp=int(dif.max()))
+        ref = rnd(emu)
+        # error in units of the bf16 ulp of the reference element; elements below 2^-12 of the tensor's largest are measured in the ulp of
+        # that floor (a sum that cancels to ~0 carries the fp32 summation-order noise of its terms, many "ulps" of a tiny result)
+        mag = torch.maximum(ref.abs(), ref.abs().max() * 2.0 ** -12).clamp_min(1e-37)
+        ulp = torch.exp2(torch.floor(torch.log2(mag)) - 7)
+        res[name] = dict(mismatch_frac=float((_mono(hip) != _mono(ref)).float().mean()), max_ulp=float(((hip - ref).abs() / ulp).max()))
 
     def f32(name, hip, ref):
         res[name] = dict(relinf=float((hip.detach().float().cpu() - ref).abs().max() / ref.abs().max()))
@@ -169,6 +174,6 @@ def test_layer0_backward_ops_on_bf16_exact_inputs(golden_dir, case):
             assert v["relinf"] <= 1e-5, (k, v)
         elif "(dw)" in k or k.startswith("bias grad"):
             # column sums over all token rows, reduced in two stages in fp32 and rounded once: a different order moves a handful of the d sums
-            assert v["max_ulp"] <= 1 and v["mismatch_frac"] <= 2e-2, (k, v)
+            assert v["max_ulp"] <= 1.0 and v["mismatch_frac"] <= 2e-2, (k, v)
         else:
-            assert v["max_ulp"] <= 1 and v["mismatch_frac"] <= 1e-3, (k, v)
+            assert v["max_ulp"] <= 1.0 and v["mismatch_frac"] <= 1e-3, (k, v)

@@ -225,3 +225,36 @@ def test_one_tile_blocks_equal_persistent_blocks():
             assert float(y1.float().abs().max()) > 0 and torch.equal(y0, y1), name
     finally:
         L.rv_gemm_select_kernel(41)
+
+
+def test_fused_adapter_pair_gemm_fast_path_is_bit_identical():
+    """BASELINE config 5 (13B LoRA): the adapter rides the base GEMM as a second operand pair ([x | t] [W | B]^T, peft LoraLayer semantics,
+    train/train.py:1515-1532).  Its buffer-addressed, persistent launch shape (the fast path) against the flat-addressed one
+    (rv_gemm_select_kernel 30 / 31) at the bench's sizes, forward (row-major W, B) and input-gradient (contraction-major W, A) forms,
+    with a residual: bit-identical; and both against an fp32 product on sampled rows."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from radvlm_amd import lib, ops
+    g = torch.Generator(device="cuda:0").manual_seed(31)
+    rn = lambda *s: (torch.randn(*s, device="cuda:0", generator=g) * 0.05).to(torch.bfloat16)
+    M, d, F, r = 22528, 5120, 13824, 64
+    L = lib.load()
+    cases = [("o_proj fwd", rn(M, d), rn(d, d), rn(M, r), rn(d, r), False, rn(M, d)),
+             ("down_proj fwd (K = 13824)", rn(M, F), rn(d, F), rn(M, r), rn(d, r), False, rn(M, d)),
+             ("gate_proj dgrad (contraction-major)", rn(M, F), rn(F, d), rn(M, r), rn(r, d), True, None),
+             ("ragged rows (M not a tile multiple)", rn(1000, d), rn(d, d), rn(1000, r), rn(d, r), False, None)]
+    try:
+        for name, a, b, a2, b2, tb, res in cases:
+            L.rv_gemm_select_kernel(31)
+            y1 = ops.gemm(a, b, tb=tb, a2=a2, b2=b2, residual=res)
+            L.rv_gemm_select_kernel(30)
+            y0 = ops.gemm(a, b, tb=tb, a2=a2, b2=b2, residual=res)
+            torch.cuda.synchronize()
+            assert torch.equal(y0, y1), name
+            rows = torch.randperm(a.shape[0], device="cuda:0", generator=g)[:256]
+            bw, b2w = (b.float(), b2.float()) if tb else (b.float().t(), b2.float().t())
+            ref = a[rows].float() @ bw + a2[rows].float() @ b2w + (res[rows].float() if res is not None else 0.0)
+            err = float((y1[rows].float() - ref).abs().max() / ref.abs().max())
+            assert err < 2.0 ** -7, (name, err)
+    finally:
+        L.rv_gemm_select_kernel(31)
