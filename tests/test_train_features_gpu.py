@@ -307,17 +307,17 @@ def test_activation_recompute_is_bit_identical(golden_dir, geo_name, golden, kw)
     from radvlm_amd.engine import LlavaEngine
     g, images = _toy_batch(golden_dir, golden)
     grads, losses = [], []
-    for rc in (False, True, 1):
-        eng = LlavaEngine(GEOMETRIES[geo_name], device="cuda:0", init="portable", seed=0, recompute=bool(rc), **kw)
-        if rc == 1:        # partial: only layer 0 recomputes
+    for rc in ("none", "all", "first"):
+        eng = LlavaEngine(GEOMETRIES[geo_name], device="cuda:0", init="portable", seed=0, recompute=rc != "none", **kw)
+        if rc == "first":        # partial: only layer 0 recomputes
             eng._recompute_layers = lambda M: 1
         if kw.get("lora"):
             for n in eng.lm.names():      # peft zero-initialises lora_B: give it values so that the adapter path carries gradient
                 if n.endswith("lora_B.weight"):
                     eng.lm.view(n).copy_(torch.randn(eng.lm.shapes[n], generator=torch.Generator().manual_seed(len(n))).to("cuda:0") * 0.05)
         loss = eng.forward(g["input_ids"], g["attention_mask"], g["labels"], images)
-        if rc:
-            assert eng.ctx["n_recomputed"] == (eng.l["layers"] if rc is True else 1)
+        if rc != "none":
+            assert eng.ctx["n_recomputed"] == (eng.l["layers"] if rc == "all" else 1)
             assert all(set(a) == {"x", "lora"} for a in eng.ctx["layers"][:eng.ctx["n_recomputed"]])
         eng.backward()
         torch.cuda.synchronize()
