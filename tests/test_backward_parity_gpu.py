@@ -104,7 +104,7 @@ def test_layer0_backward_ops_on_bf16_exact_inputs(golden_dir, case):
     rows = valid.reshape(-1)
     up = lambda t: t.reshape(-1, t.shape[-1]).to(torch.bfloat16).to(dev).contiguous()
     lv = eng._layer_views(0)
-    res = {}
+    res, WORST = {}, {}
 
     def bf(name, hip, emu, all_rows=False):
         hip = hip.detach().float().cpu().reshape(-1, emu.shape[-1])
@@ -117,6 +117,9 @@ def test_layer0_backward_ops_on_bf16_exact_inputs(golden_dir, case):
         mag = torch.maximum(ref.abs(), ref.abs().max() * 2.0 ** -12).clamp_min(1e-37)
         ulp = torch.exp2(torch.floor(torch.log2(mag)) - 7)
         err = (hip - ref).abs() / ulp
+        w = int(err.reshape(-1).argmax())
+        WORST[name] = dict(row=w // ref.shape[-1], col=w % ref.shape[-1], hip=float(hip.reshape(-1)[w]), ref=float(ref.reshape(-1)[w]),
+                           tensor_max=float(ref.abs().max()), n_gt_1ulp=int((err > 1.0).sum()))
         res[name] = dict(mismatch_frac=float((err > 0.5).float().mean()), max_ulp=float(err.max()), bitwise_mismatch_frac=float((_mono(hip) != _mono(ref)).float().mean()))
 
     def f32(name, hip, ref):
@@ -129,6 +132,8 @@ def test_layer0_backward_ops_on_bf16_exact_inputs(golden_dir, case):
     f32("wgrad down_proj", ops.gemm(dxo, act, ta=True, tb=True, out_dtype=F32), R["gW_down"])
     dact = ops.gemm(dxo, lv["down"], tb=True)
     bf("swiglu bwd (unfused: dgrad + rv_swiglu_bwd)", ops.swiglu_bwd(dact, gu, F_), R["dgu"])
+    dact_e = rnd(torch.nn.functional.linear(dx_out, Pr[pre + "mlp.down_proj.weight"].t()))
+    bf("rv_swiglu_bwd on the emulated d(act)", ops.swiglu_bwd(up(dact_e), gu, F_), R["dgu"])
     lib.load().rv_gemm_select_kernel(2)        # the fused epilogue lives in the 256x256 kernel, which small M would not select
     try:
         bf("swiglu bwd (fused rv_gemm_swiglu_bwd_bf16)", ops.gemm_swiglu_bwd(dxo, lv["down"], gu, F_), R["dgu"])
@@ -166,6 +171,7 @@ def test_layer0_backward_ops_on_bf16_exact_inputs(golden_dir, case):
     bf("rmsnorm bwd 1 (dw)", g1.view(1, -1), R["g_ln1"].view(1, -1), all_rows=True)
     torch.cuda.synchronize()
     RESULTS[case] = res
+    RESULTS[case + " (worst element)"] = WORST
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/bf16_backward_parity.json", "w") as f:
         json.dump(RESULTS, f, indent=1)
@@ -176,5 +182,9 @@ def test_layer0_backward_ops_on_bf16_exact_inputs(golden_dir, case):
         elif "(dw)" in k or k.startswith("bias grad"):
             # column sums over all token rows, reduced in two stages in fp32 and rounded once: a different order moves a handful of the d sums
             assert v["max_ulp"] <= 1.0 and v["mismatch_frac"] <= 2e-2, (k, v)
+        elif k.startswith("swiglu bwd"):
+            # two store points in one op (d(act) rounded, then d gate / d up): an element whose d(act) flipped by one ulp carries that
+            # 2^-8..2^-7 relative step into its outputs -- up to 3 ulps there, still in <= 1e-3 of the elements
+            assert v["max_ulp"] <= 3.0 and v["mismatch_frac"] <= 1e-3, (k, v)
         else:
             assert v["max_ulp"] <= 1.0 and v["mismatch_frac"] <= 1e-3, (k, v)
