@@ -264,8 +264,8 @@ DEVINL void stage_half(const bf16* __restrict__ src, long ld, int feat0, int nfe
 // so a staging piece costs an M0 write and the load itself -- the flat form spent a 64-bit vector add, a range compare and two selects
 // per piece (the zero-page source select) in front of every one of the 8 pieces a wave issues per K-tile.  Rows past the end of the
 // operand (tile edges, K tails of contraction-major operands) are out of the resource's range and read as zero in hardware.
-// Requirements checked on the host: operand extent < 2 GiB; for a row-major operand K % 64 == 0 (a K tail inside a row is not a
-// resource boundary), otherwise the flat path runs.
+// Requirements checked on the host: operand extent < 2 GiB; K % 64 == 0 unless BOTH operands are contraction-major (a K tail inside
+// the rows of a row-major operand is not a resource boundary), otherwise the flat path runs.
 struct HalfPlan { int v[2]; };
 template <bool T, bool PERM, int BMAP>
 DEVINL HalfPlan plan_half(long ld, int feat0, int nfeat, int wid, int lane, int h, int F, unsigned limit) {
@@ -1118,14 +1118,16 @@ static int cu_budget() {
 
 // Operand extents for the buffer-addressed kernels; false when a shape does not qualify (K tail inside a row, >= 2 GiB operand).
 static bool buf_extents(GemmParams& P, int trans_a, int trans_b) {
-    if (P.K % BK) return false;
+    // a K tail is a resource boundary only for contraction-major operands (whole rows past the end read as zero); inside the rows of a
+    // row-major operand it is not -- e.g. the weight gradients of a 14998-token batch (both operands contraction-major) qualify
+    if ((P.K % BK) && !(trans_a && trans_b)) return false;
     const long ea = (trans_a ? (long)P.K : (long)P.M) * P.lda * 2, eb = (trans_b ? (long)P.K : (long)P.N) * P.ldb * 2;
     if (ea >= (1L << 31) || eb >= (1L << 31) || g_no_buf) return false;
     P.bytesA = (unsigned)ea; P.bytesB = (unsigned)eb;
     return true;
 }
 static bool buf_extents2(GemmParams& P, int trans_a, int trans_b) {
-    if (P.K2 % BK) return false;
+    if ((P.K2 % BK) && !(trans_a && trans_b)) return false;
     const long ea = (trans_a ? (long)P.K2 : (long)P.M) * P.lda2 * 2, eb = (trans_b ? (long)P.K2 : (long)P.N) * P.ldb2 * 2;
     if (ea >= (1L << 31) || eb >= (1L << 31)) return false;
     P.bytesA2 = (unsigned)ea; P.bytesB2 = (unsigned)eb;

@@ -258,3 +258,32 @@ def test_fused_adapter_pair_gemm_fast_path_is_bit_identical():
             assert err < 2.0 ** -7, (name, err)
     finally:
         L.rv_gemm_select_kernel(31)
+
+
+def test_weight_gradient_with_a_token_count_that_is_no_tile_multiple():
+    """The recipe batch of SURVEY 8f.1 has 2 x 7499 = 14998 token rows: the weight gradients contract over a K that is not a multiple of
+    the 64-deep K-tile.  With both operands contraction-major the tail rows lie past the end of the buffer resource and read as zero in
+    hardware, so the buffer-addressed / persistent launch shape applies (rv_gemm_select_kernel 31) -- bit-identical to the flat-addressed
+    one (30) and equal to an fp32 product; plain (MODE 0) and tail-split (MODE 3) outputs."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from radvlm_amd import lib, ops
+    g = torch.Generator(device="cuda:0").manual_seed(41)
+    rn = lambda *s: (torch.randn(*s, device="cuda:0", generator=g) * 0.05).to(torch.bfloat16)
+    L = lib.load()
+    try:
+        for name, M, N, K in (("q|k|v wgrad, Qwen2 widths (MODE 0)", 4608, 3584, 14998), ("gate|up wgrad (tail split)", 37888, 3584, 14998),
+                              ("tower fc1 wgrad, K = 14580", 4304, 1152, 14580)):
+            dy, x = rn(K, M), rn(K, N)
+            L.rv_gemm_select_kernel(31)
+            y1 = ops.gemm(dy, x, ta=True, tb=True)
+            L.rv_gemm_select_kernel(30)
+            y0 = ops.gemm(dy, x, ta=True, tb=True)
+            torch.cuda.synchronize()
+            assert torch.equal(y0, y1), name
+            rows = torch.randperm(M, device="cuda:0", generator=g)[:128]
+            ref = dy[:, rows].float().t() @ x.float()
+            err = float((y1[rows].float() - ref).abs().max() / ref.abs().max())
+            assert err < 2.0 ** -7, (name, err)
+    finally:
+        L.rv_gemm_select_kernel(31)
