@@ -6,7 +6,10 @@ input gradients (`rv_gemm_bf16` row x contraction-major), the SwiGLU backward fu
 (`rv_gemm_swiglu_bwd_bf16`) and its unfused sequence, `rv_rmsnorm_bwd`, `rv_attn_bwd_nat` (dQ, dK, dV with the rotary adjoint) -- is run on
 the inputs the emulated backward chain (oracle/bf16_emulation.py::decoder_layer_backward, pinned to torch autograd of the reference-pinned
 oracle by tests/test_oracle_golden.py) feeds it, and must reproduce that op's emulated output:
-  bf16 outputs : at most 1e-3 of the elements differ, each by one ulp (an fp32 sum of a different order straddling a rounding boundary;
+  bf16 outputs of single-rounding ops (input-gradient GEMMs, RMSNorm backward, the SwiGLU kernel on a given d(act)) : at most 1e-3 of the
+                 elements differ, each by one ulp; ops with internal bf16 store points get the tolerances stated at the asserts
+                 (fused SwiGLU backward: 3 ulps; attention backward: flipped fraction <= 2e-3, every error <= 2^-10 of the tensor maximum)
+  [one ulp]    :  (an fp32 sum of a different order straddling a rounding boundary;
                  elements smaller than 2^-12 of the tensor's largest are measured in the ulp of that floor);
   fp32 weight-gradient sums (GEMM with out_f32) : ||d||_inf / ||ref||_inf <= 1e-5 against a float64 product.
 A 3 % error in any backward kernel fails here (the end-to-end gradient gates cannot see that: bf16 noise through the layers is of that order).
@@ -120,7 +123,8 @@ def test_layer0_backward_ops_on_bf16_exact_inputs(golden_dir, case):
         w = int(err.reshape(-1).argmax())
         WORST[name] = dict(row=w // ref.shape[-1], col=w % ref.shape[-1], hip=float(hip.reshape(-1)[w]), ref=float(ref.reshape(-1)[w]),
                            tensor_max=float(ref.abs().max()), n_gt_1ulp=int((err > 1.0).sum()))
-        res[name] = dict(mismatch_frac=float((err > 0.5).float().mean()), max_ulp=float(err.max()), bitwise_mismatch_frac=float((_mono(hip) != _mono(ref)).float().mean()))
+        res[name] = dict(mismatch_frac=float((err > 0.5).float().mean()), max_ulp=float(err.max()), bitwise_mismatch_frac=float((_mono(hip) != _mono(ref)).float().mean()),
+                         max_abs_err_over_tensor_max=float((hip - ref).abs().max() / ref.abs().max()))
 
     def f32(name, hip, ref):
         res[name] = dict(relinf=float((hip.detach().float().cpu() - ref).abs().max() / ref.abs().max()))
@@ -182,6 +186,12 @@ def test_layer0_backward_ops_on_bf16_exact_inputs(golden_dir, case):
         elif "(dw)" in k or k.startswith("bias grad"):
             # column sums over all token rows, reduced in two stages in fp32 and rounded once: a different order moves a handful of the d sums
             assert v["max_ulp"] <= 1.0 and v["mismatch_frac"] <= 2e-2, (k, v)
+        elif k.startswith("attention bwd"):
+            # internal store points (P and dS are rounded to bf16 before their MFMA products, dQ / dK once more before the rotary adjoint):
+            # one flipped dS element moves a dQ element by ulp(dS) * |k| * scale -- invisible on a typical element, many "ulps" of an
+            # element that is itself ~0.  Gate: the flipped fraction, and every error below 2^-10 of the tensor's largest element
+            # (measured 1.2e-4 .. 4e-4; a 3 % kernel error would put ALL elements far above both)
+            assert v["mismatch_frac"] <= 2e-3 and v["max_abs_err_over_tensor_max"] <= 2.0 ** -10, (k, v)
         elif k.startswith("swiglu bwd"):
             # two store points in one op (d(act) rounded, then d gate / d up): an element whose d(act) flipped by one ulp carries that
             # 2^-8..2^-7 relative step into its outputs -- up to 3 ulps there, still in <= 1e-3 of the elements

@@ -35,8 +35,9 @@ GRAD_REL_L2 = 0.22            # per tensor ||g_hip - g_fp32||_2 / ||g_fp32||_2: 
                               # bf16-EMULATING oracle itself misses by 5.7 % (emu_vs_fp32_l2); kernel errors proper are gated per op in
                               # tests/test_backward_parity_gpu.py
 GRAD_NORM_REL = 5e-3          # global gradient norm (measured 8e-4, 1.2e-3)
-UPDATE_MEAN = 0.15            # mean |master_hip - p_fp32| / lr per tensor after two steps (an AdamW update is <= ~1 lr per step)
-UPDATE_FRAC_BAD = 5e-2        # fraction of a tensor's elements whose two-step update differs by more than 0.5 lr
+UPDATE_MEAN = 0.25            # mean |master_hip - master_fp32| / lr per tensor after two steps (an AdamW update is <= ~1 lr per step; a slice
+                              # that was zeroed, skipped or updated with a wrong gradient reads ~1 .. 1e3 here)
+UPDATE_FRAC_BAD = 0.10        # fraction of a tensor's elements whose two-step update differs by more than 0.5 lr
 
 
 def _avail_gb():
@@ -195,12 +196,12 @@ def test_config2_full_size_forward_backward_two_adamw_steps():
             worst_mean = (mean, k)
         if bad > worst_bad[0]:
             worst_bad = (bad, k)
-        assert mean <= UPDATE_MEAN and bad <= UPDATE_FRAC_BAD, (k, mean, bad)
     rec.update(update_worst_mean_over_lr=worst_mean, update_worst_frac_gt_half_lr=worst_bad,
                seconds=time.time() - t_start, lr=lr, weight_decay=wd, max_grad_norm=clip)
     record_measurement("config2_full_size", **rec)
     dump()
     print(json.dumps(rec))
+    assert worst_mean[0] <= UPDATE_MEAN and worst_bad[0] <= UPDATE_FRAC_BAD, (worst_mean, worst_bad)
     # 108 GB of device memory and 135 GB of host memory: hand them back before the next test of this process
     del eng, P, M, Vv, MASTER
     import gc
