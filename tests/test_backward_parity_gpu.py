@@ -6,11 +6,11 @@ input gradients (`rv_gemm_bf16` row x contraction-major), the SwiGLU backward fu
 (`rv_gemm_swiglu_bwd_bf16`) and its unfused sequence, `rv_rmsnorm_bwd`, `rv_attn_bwd_nat` (dQ, dK, dV with the rotary adjoint) -- is run on
 the inputs the emulated backward chain (oracle/bf16_emulation.py::decoder_layer_backward, pinned to torch autograd of the reference-pinned
 oracle by tests/test_oracle_golden.py) feeds it, and must reproduce that op's emulated output:
-  bf16 outputs of single-rounding ops (input-gradient GEMMs, RMSNorm backward, the SwiGLU kernel on a given d(act)) : at most 1e-3 of the
-                 elements differ, each by one ulp; ops with internal bf16 store points get the tolerances stated at the asserts
-                 (fused SwiGLU backward: 3 ulps; attention backward: flipped fraction <= 2e-3, every error <= 2^-10 of the tensor maximum)
-  [one ulp]    :  (an fp32 sum of a different order straddling a rounding boundary;
-                 elements smaller than 2^-12 of the tensor's largest are measured in the ulp of that floor);
+  bf16 outputs of single-rounding ops (input-gradient GEMMs, RMSNorm backward, the SwiGLU kernel on a given d(act)): at most 1e-3 of the
+      elements differ, each by one ulp (an fp32 sum of a different order straddling a rounding boundary; elements smaller than 2^-12 of
+      the tensor's largest are measured in the ulp of that floor);
+  ops with internal bf16 store points: the tolerances stated at the asserts (fused SwiGLU backward: 3 ulps; attention backward: flipped
+      fraction <= 2e-3 and every error <= 2^-10 of the tensor's largest element);
   fp32 weight-gradient sums (GEMM with out_f32) : ||d||_inf / ||ref||_inf <= 1e-5 against a float64 product.
 A 3 % error in any backward kernel fails here (the end-to-end gradient gates cannot see that: bf16 noise through the layers is of that order).
 """
