@@ -19,7 +19,8 @@ Store points followed (reference text each one shadows):
   LayerNorm / RMSNorm output           modeling_llama.py:84-87 (normalised value rounded, then * weight, rounded)
   RoPE                                 cos/sin rounded (modeling_llama.py:134-139 ``.to(dtype=x.dtype)``), rotation in fp32, one rounding
   attention                            scores / softmax statistics fp32 (modeling_llama.py:361 softmax(dtype=float32)), probabilities
-                                       rounded to bf16 before P V, 64-key tiles with a running maximum, output rounded once
+                                       rounded to bf16 before P V, 64-key tiles with a running maximum (head_dim 128 kernels: the
+                                       maximum rounded up to an integer of the exp2 domain), output rounded once
   SwiGLU                               silu(gate) rounded, * up, rounded (modeling_llama.py:226)
   logits                               bf16 (lm_head output), read back as fp32 for the loss (modeling_llama.py:1324 logits.float())
 """
@@ -69,9 +70,16 @@ def rope(x, cos, sin, rnd):
     return rnd(torch.cat((a * cos - b * sin, b * cos + a * sin), dim=-1))
 
 
-def attention(q, k, v, lens, causal, scale, rnd, pos0=None, tile=64):
-    """Flash-style attention as the kernel evaluates it: per 64-key tile, running maximum in the exp2 domain, probabilities rounded
-    before the P V product, fp32 accumulators, one rounding of O / l.  With rnd = identity it is plain softmax attention."""
+def nat_kernel_head_dim(hd):
+    """True when the engine runs this head_dim on the natural-layout attention kernels (head_dim 128, or padded to 128): those keep
+    the running maximum as an integer of the exp2 domain (radvlm_amd/csrc/attention.hip, attn_fwd_nat_kernel)."""
+    return (hd if hd in (64, 128) else (64 if hd < 64 else 128)) == 128
+
+
+def attention(q, k, v, lens, causal, scale, rnd, pos0=None, tile=64, int_max=False):
+    """Flash-style attention as the kernel evaluates it: per 64-key tile, running maximum in the exp2 domain (int_max: rounded up to
+    an integer, as the natural-layout kernels keep it -- every rescale is then an exact power of two), probabilities rounded before
+    the P V product, fp32 accumulators, one rounding of O / l.  With rnd = identity it is plain softmax attention."""
     b, h, S, hd = q.shape
     sl2 = scale * LOG2E
     o = torch.zeros(b, h, S, hd)
@@ -89,7 +97,8 @@ def attention(q, k, v, lens, causal, scale, rnd, pos0=None, tile=64):
         if lens is not None:
             ok = ok & (ki[None, None] < torch.as_tensor(lens)[:, None, None, None])
         s = torch.where(ok, s, torch.full_like(s, -math.inf))
-        mnew = torch.maximum(m, s.amax(-1, keepdim=True))
+        tmax = s.amax(-1, keepdim=True)
+        mnew = torch.maximum(m, torch.ceil(tmax) if int_max else tmax)
         safe = torch.where(torch.isinf(mnew), torch.zeros_like(mnew), mnew)      # rows with no valid key so far
         alpha = torch.exp2(m - safe)
         p = torch.exp2(s - safe)
@@ -115,7 +124,7 @@ def decoder_layer(x, P, pre, l, lens, cos, sin, eps, rnd):
     if kvh != heads:
         k = k.repeat_interleave(heads // kvh, dim=1)
         v = v.repeat_interleave(heads // kvh, dim=1)
-    a = _t(pre + "attn", attention(q, k, v, lens, True, 1.0 / math.sqrt(hd), rnd).transpose(1, 2).reshape(b, S, d))
+    a = _t(pre + "attn", attention(q, k, v, lens, True, 1.0 / math.sqrt(hd), rnd, int_max=nat_kernel_head_dim(hd)).transpose(1, 2).reshape(b, S, d))
     x_mid = _t(pre + "x_mid", rnd(F.linear(a, P[pre + "self_attn.o_proj.weight"]) + x))
     h2 = _t(pre + "h2", rmsnorm(x_mid, P[pre + "post_attention_layernorm.weight"], eps, rnd))
     g = rnd(F.linear(h2, P[pre + "mlp.gate_proj.weight"]))
@@ -167,7 +176,7 @@ def vision_tower(P, geo, pixels, rnd, fused_act=True):
         h = layernorm(x, P[p + "layer_norm1.weight"], P[p + "layer_norm1.bias"], eps, rnd)
         q, k, vv = (rnd(F.linear(h, P[p + f"self_attn.{t}_proj.weight"], P[p + f"self_attn.{t}_proj.bias"])).view(n, N, H, hd).transpose(1, 2)
                     for t in "qkv")
-        a = attention(q, k, vv, None, False, hd ** -0.5, rnd).transpose(1, 2).reshape(n, N, d)
+        a = attention(q, k, vv, None, False, hd ** -0.5, rnd, int_max=nat_kernel_head_dim(hd)).transpose(1, 2).reshape(n, N, d)
         x = rnd(F.linear(a, P[p + "self_attn.out_proj.weight"], P[p + "self_attn.out_proj.bias"]) + x)
         h = layernorm(x, P[p + "layer_norm2.weight"], P[p + "layer_norm2.bias"], eps, rnd)
         z = F.linear(h, P[p + "mlp.fc1.weight"], P[p + "mlp.fc1.bias"])

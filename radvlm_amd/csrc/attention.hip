@@ -534,6 +534,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
         for (int qs = 0; qs < 2; ++qs) mxa[qs] = max3_asm(mxa[qs], s[qs][3][2], s[qs][3][3]);
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) mxa[qs] = max3_asm(mxa[qs], mxb[qs], mxb[qs]);
+        // Running maximum kept as an INTEGER of the exp2 domain (ceil of the scaled row maximum): every rescale factor is then an exact
+        // power of two, so WHEN a row is rescaled does not change a bit of the result -- and it is deferred until some row of the wave has
+        // outgrown its stored maximum by more than 2^RESCALE_LAG (p then stays <= 2^RESCALE_LAG: nothing for fp32 sums or bf16 P).  After
+        // the first tile that practically never happens, and the 64 accumulator multiplies + 2 exp per tile (a third of the tile's VALU
+        // issue cycles; the loop was VALU-bound: 182 VALU for 64 MFMA per tile) leave the loop.
+#ifdef RV_ATTN_REAL_MAX        // A/B switch (measurement only): round 2's real-valued running maximum, rescaled every tile
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
             float mx = mxa[qs];
@@ -541,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
             mx = max3_asm(mx, sh, sh);
             sh = __shfl_xor(mx, 32, 64);
             mx = max3_asm(mx, sh, sh);
-            const float ms = mx * sl2;                        // scale > 0: the maximum commutes with the scaling
+            const float ms = mx * sl2;
             const float mnew = max3_asm(m[qs], ms, ms);
             const float alpha = fexp2(m[qs] - mnew);
             float rs = 0.f;
@@ -558,6 +564,45 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
 #pragma unroll
             for (int db = 0; db < DB; ++db) o[qs][db] *= alpha;
         }
+#else
+        constexpr float RESCALE_LAG = 8.f;
+        float cand[2];
+        bool need = false;
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            float mx = mxa[qs];
+            float sh = __shfl_xor(mx, 16, 64);
+            mx = max3_asm(mx, sh, sh);
+            sh = __shfl_xor(mx, 32, 64);
+            mx = max3_asm(mx, sh, sh);
+            cand[qs] = ceilf(mx * sl2);                       // scale > 0: the maximum commutes with the scaling
+            need |= cand[qs] > m[qs] + RESCALE_LAG;           // m = -inf before the first tile
+        }
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {         // wave-uniform
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) {
+                const float mnew = max3_asm(m[qs], cand[qs], cand[qs]);
+                const float alpha = fexp2(m[qs] - mnew);      // 2^(integer) or 0
+                l[qs] *= alpha;
+                m[qs] = mnew;
+#pragma unroll
+                for (int db = 0; db < DB; ++db) o[qs][db] *= alpha;
+            }
+        }
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = fexp2(__builtin_fmaf(s[qs][kb][r], sl2, -m[qs]));
+                    s[qs][kb][r] = p;
+                    rs += p;
+                }
+            l[qs] += rs;
+        }
+#endif
         if (LATE) plV.stage(rsV, (t + 1) * vstep + hoff, nx + TILE, wid);
         // O^T[d][q] += V^T[d][key] P^T[key][q]
         {

@@ -733,6 +733,11 @@ class LlavaEngine:
         acc = self.grad_accum_started
         ws = self._lora_ws()
         dx = None
+        if self.lora_p > 0 and len(mods) > 1:
+            # base path of a fused projection (q|k|v, gate|up): ONE input-gradient GEMM over the stacked frozen weight, dx = dy W, instead of
+            # one per module accumulated through the residual (two fewer passes over dx, one long K loop); the adapters add into it below
+            dx = ops.gemm(dy[:, mods[0][1]:mods[-1][2]], w[mods[0][1]:mods[-1][2]], tb=True)
+        base_done = dx is not None
         for lname, c0, c1 in mods:
             pre = f"model.layers.{i}.{lname}."
             A, B = self.W(pre + "lora_A.weight"), self.W(pre + "lora_B.weight")
@@ -747,7 +752,8 @@ class LlavaEngine:
             if self.lora_p > 0:
                 seed = self._lora_seed(i, lname)
                 ops.gemm(dts, ops.dropout(x, self.lora_p, seed), ta=True, tb=True, out=gA, residual=gA if acc else None, workspace=ws)
-                ops.gemm(dyj, w[c0:c1], tb=True, out=dx, residual=None if first else dx)
+                if not base_done:
+                    ops.gemm(dyj, w[c0:c1], tb=True, out=dx, residual=None if first else dx)
                 ops.dropout_add(ops.gemm(dts, A, tb=True), dx, self.lora_p, seed)   # dx += dropout'(dts A), one pass
             else:
                 ops.gemm(dts, x, ta=True, tb=True, out=gA, residual=gA if acc else None, workspace=ws)

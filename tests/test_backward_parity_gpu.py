@@ -10,7 +10,7 @@ oracle by tests/test_oracle_golden.py) feeds it, and must reproduce that op's em
       elements differ, each by one ulp (an fp32 sum of a different order straddling a rounding boundary; elements smaller than 2^-12 of
       the tensor's largest are measured in the ulp of that floor);
   ops with internal bf16 store points: the tolerances stated at the asserts (fused SwiGLU backward: 3 ulps; attention backward: flipped
-      fraction <= 2e-3 and every error <= 2^-10 of the tensor's largest element);
+      fraction <= 2e-3, ulp floored at that of 2^-4 of the tensor's largest element);
   fp32 weight-gradient sums (GEMM with out_f32) : ||d||_inf / ||ref||_inf <= 1e-5 against a float64 product.
 A 3 % error in any backward kernel fails here (the end-to-end gradient gates cannot see that: bf16 noise through the layers is of that order).
 """
@@ -109,7 +109,7 @@ def test_layer0_backward_ops_on_bf16_exact_inputs(golden_dir, case):
     lv = eng._layer_views(0)
     res, WORST = {}, {}
 
-    def bf(name, hip, emu, all_rows=False):
+    def bf(name, hip, emu, all_rows=False, floor_exp=-12):
         hip = hip.detach().float().cpu().reshape(-1, emu.shape[-1])
         emu = emu.reshape(-1, emu.shape[-1])
         if not all_rows:
@@ -117,7 +117,7 @@ def test_layer0_backward_ops_on_bf16_exact_inputs(golden_dir, case):
         ref = rnd(emu)
         # error in units of the bf16 ulp of the reference element; elements below 2^-12 of the tensor's largest are measured in the ulp of
         # that floor (a sum that cancels to ~0 carries the fp32 summation-order noise of its terms, many "ulps" of a tiny result)
-        mag = torch.maximum(ref.abs(), ref.abs().max() * 2.0 ** -12).clamp_min(1e-37)
+        mag = torch.maximum(ref.abs(), ref.abs().max() * 2.0 ** floor_exp).clamp_min(1e-37)
         ulp = torch.exp2(torch.floor(torch.log2(mag)) - 7)
         err = (hip - ref).abs() / ulp
         w = int(err.reshape(-1).argmax())
@@ -164,7 +164,7 @@ def test_layer0_backward_ops_on_bf16_exact_inputs(golden_dir, case):
                  dq=dqkv[:, :d], dk=dqkv[:, d:d + kvd], dv=dqkv[:, d + kvd:], kv_heads=Hkv, rope=(eng.rope_table(S), None),
                  use_workspace=partials)
     for nm, c0, c1 in (("dQ", 0, d), ("dK", d, d + kvd), ("dV", d + kvd, d + 2 * kvd)):
-        bf(f"attention bwd {nm} (rv_attn_bwd_nat, rope adjoint)", dqkv[:, c0:c1], R["dqkv"][..., c0:c1])
+        bf(f"attention bwd {nm} (rv_attn_bwd_nat, rope adjoint)", dqkv[:, c0:c1], R["dqkv"][..., c0:c1], floor_exp=-4)
     dqkv_e = up(R["dqkv"])
     if l.get("qkv_bias"):
         bf("bias grad q|k|v", ops.bias_grad(dqkv_e).view(1, -1), R["g_bqkv"].view(1, -1), all_rows=True)
@@ -188,10 +188,10 @@ def test_layer0_backward_ops_on_bf16_exact_inputs(golden_dir, case):
             assert v["max_ulp"] <= 1.0 and v["mismatch_frac"] <= 2e-2, (k, v)
         elif k.startswith("attention bwd"):
             # internal store points (P and dS are rounded to bf16 before their MFMA products, dQ / dK once more before the rotary adjoint):
-            # one flipped dS element moves a dQ element by ulp(dS) * |k| * scale -- invisible on a typical element, many "ulps" of an
-            # element that is itself ~0.  Gate: the flipped fraction, and every error below 2^-10 of the tensor's largest element
-            # (measured 1.2e-4 .. 4e-4; a 3 % kernel error would put ALL elements far above both)
-            assert v["mismatch_frac"] <= 2e-3 and v["max_abs_err_over_tensor_max"] <= 2.0 ** -10, (k, v)
+            # one flipped dS element moves a dQ element by ulp(dS) * |k| * scale -- invisible on a typical element, many ulps of an
+            # element that is itself ~0.  So the ulp is floored at that of 2^-4 of the tensor's largest element (measured worst error:
+            # 2^-13 of the largest element); a 3 % kernel error is 4 .. 8 ulps on every element above that floor
+            assert v["mismatch_frac"] <= 2e-3 and v["max_ulp"] <= 1.0, (k, v)
         elif k.startswith("swiglu bwd"):
             # two store points in one op (d(act) rounded, then d gate / d up): an element whose d(act) flipped by one ulp carries that
             # 2^-8..2^-7 relative step into its outputs -- up to 3 ulps there, still in <= 1e-3 of the elements

@@ -264,8 +264,11 @@ def test_bf16_emulated_parity(golden_dir, name, geo_name):
     qkv_e = up(torch.cat((T[p0 + "q_roped"], T[p0 + "k_roped"], T[p0 + "v"]), -1))
     s_pad = (S + 63) // 64 * 64
     lens_t = torch.tensor(aux["lens"], dtype=torch.int32, device=dev)
-    vT = ops.transpose_heads(qkv_e[:, d + kvd:], B, S, Hkv, hd, s_pad)
-    attn, _ = ops.attn_fwd(qkv_e[:, :d], qkv_e[:, d:d + kvd], vT, B, S, H, hd, s_pad, causal=True, lens=lens_t, kv_heads=Hkv)
+    if hd == 128:      # the kernel the engine runs for head_dim 128 (natural layout, integer running maximum)
+        attn, _ = ops.attn_fwd(qkv_e[:, :d], qkv_e[:, d:d + kvd], None, B, S, H, hd, s_pad, causal=True, lens=lens_t, kv_heads=Hkv, v=qkv_e[:, d + kvd:])
+    else:
+        vT = ops.transpose_heads(qkv_e[:, d + kvd:], B, S, Hkv, hd, s_pad)
+        attn, _ = ops.attn_fwd(qkv_e[:, :d], qkv_e[:, d:d + kvd], vT, B, S, H, hd, s_pad, causal=True, lens=lens_t, kv_heads=Hkv)
     forced["attention"] = mism(attn, T[p0 + "attn"])
     forced["o_proj + residual"] = mism(ops.gemm_nt(up(T[p0 + "attn"]), lv["o"], residual=x_e), T[p0 + "x_mid"])
     h2, _ = ops.rmsnorm_fwd(up(T[p0 + "x_mid"]), lv["ln2"], eng.eps)
