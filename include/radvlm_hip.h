@@ -32,7 +32,8 @@ const char* rv_version(void);
  * C[M,N] = act(A[M,K] * B[N,K]^T + bias[N]) + residual[M,N]          (bf16 in, fp32 accumulate)
  * = torch.nn.functional.linear at: modeling_llama.py:332-338,377 (q/k/v/o), :226 (gate/up/down), :1323 (lm_head);
  *   HF:models/clip/modeling_clip.py:298-350 (CLIP q/k/v/out/fc1/fc2), :209 (patch conv as GEMM over im2col rows);
- *   multimodal_projector/builder.py:41-48.  Backward (dgrad/wgrad) uses the same entry with transposed copies.
+ *   multimodal_projector/builder.py:41-48.  Backward (dgrad / wgrad) goes through rv_gemm_bf16 below, which reads its operands
+ *   contraction-major in place (no transposed copies).
  * K % 8 == 0, lda % 8 == 0, ldb % 8 == 0.  out_f32: C is fp32 (else bf16).  residual may alias C (accumulate).
  */
 int rv_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,

@@ -4,7 +4,8 @@
 // Replaces (reference call sites): every nn.Linear / F.linear of the hot path -- HF Llama q/k/v/o/gate/up/down
 // (finetuning/llava/model/language_model/modeling_llama.py:332-338,377,226), lm_head (:1323), CLIP q/k/v/out/fc1/fc2
 // (HF:models/clip/modeling_clip.py:298-350), patch-embed conv as GEMM (:209), mm_projector
-// (multimodal_projector/builder.py:41-48) and their autograd dgrad/wgrad (fed with transposed copies).
+// (multimodal_projector/builder.py:41-48) and their autograd dgrad / wgrad (the contraction-major operand forms of the 256x256 kernel
+// below read activations and weights in place: no transposed copies).
 //
 // Structure (v1): 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 tiles,
 // LDS-DMA staging (global_load_lds 16 B) into a 2-stage ring, XOR-swizzled 128-B rows so that the
@@ -1080,6 +1081,7 @@ __global__ __launch_bounds__(256) void tail_reduce_kernel(GemmParams P) {
 static int g_tail_split = 1;   // rv_gemm_select_kernel(20) disables the tail split (A/B), (21) enables
 static int g_force_kernel = 0;  // 0 auto, 1 = 128x128 kernel, 2 = 256x256 kernel (RV_GEMM_KERNEL or rv_gemm_select_kernel)
 static int g_cus = 0;           // 0 = not yet queried
+static int g_cus_device = -1;   // the device g_cus was derived for: a process that switches devices re-queries (one process normally drives one GPU)
 static int g_reserved_cus = -1; // -1 = take RV_GEMM_RESERVED_CUS (default 0) at first use
 static int g_no_buf = 0;         // rv_gemm_select_kernel(30 / 31): buffer-addressed staging off / on (A/B measurement)
 static int g_persist = 1;        // rv_gemm_select_kernel(40 / 41): persistent tile-walking blocks off / on.  OFF when collectives share the GPU
@@ -1096,12 +1098,14 @@ extern "C" int rv_gemm_select_kernel(int which) {
 // (hipDeviceProp_t::multiProcessorCount of the current device); reserved_cus: units left to other streams (an RCCL all-reduce
 // overlapped with backward occupies a few dozen), subtracted from the total.  Returns the resulting budget.
 extern "C" int rv_gemm_set_cu_budget(int total_cus, int reserved_cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return RV_ERR_LAUNCH;
     if (total_cus <= 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return RV_ERR_LAUNCH;
-        total_cus = prop.multiProcessorCount;
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return RV_ERR_LAUNCH;
+        total_cus = n;
     }
+    g_cus_device = dev;
     if (reserved_cus < 0) reserved_cus = 0;
     g_reserved_cus = reserved_cus;
     g_cus = total_cus - reserved_cus;
@@ -1109,6 +1113,8 @@ extern "C" int rv_gemm_set_cu_budget(int total_cus, int reserved_cus) {
     return g_cus;
 }
 static int cu_budget() {
+    int dev = 0;
+    if (g_cus != 0 && hipGetDevice(&dev) == hipSuccess && dev != g_cus_device) g_cus = 0;     // another device became current: plan for ITS units
     if (g_cus == 0) {
         const char* e = getenv("RV_GEMM_RESERVED_CUS");
         rv_gemm_set_cu_budget(0, g_reserved_cus >= 0 ? g_reserved_cus : (e ? atoi(e) : 0));

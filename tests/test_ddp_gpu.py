@@ -59,8 +59,12 @@ def test_engine_ddp_two_ranks_one_gpu(tmp_path, geo, gold, kw):
     script = tmp_path / "w.py"
     script.write_text(WORKER.format(root=ROOT, geo=geo, gold=gold, kw=kw))
     procs = []
+    import socket
+    with socket.socket() as sock:        # a free rendezvous port (a fixed one collides with a concurrent or lingering run)
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     for p in procs:
         out, err = p.communicate(timeout=600)
