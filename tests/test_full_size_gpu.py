@@ -35,9 +35,9 @@ GRAD_REL_L2 = 0.22            # per tensor ||g_hip - g_fp32||_2 / ||g_fp32||_2: 
                               # bf16-EMULATING oracle itself misses by 5.7 % (emu_vs_fp32_l2); kernel errors proper are gated per op in
                               # tests/test_backward_parity_gpu.py
 GRAD_NORM_REL = 5e-3          # global gradient norm (measured 8e-4, 1.2e-3)
-UPDATE_MEAN = 0.25            # mean |master_hip - master_fp32| / lr per tensor after two steps (an AdamW update is <= ~1 lr per step; a slice
-                              # that was zeroed, skipped or updated with a wrong gradient reads ~1 .. 1e3 here)
-UPDATE_FRAC_BAD = 0.10        # fraction of a tensor's elements whose two-step update differs by more than 0.5 lr
+UPDATE_MEAN = 0.21            # mean |master_hip - master_fp32| / lr per tensor after two steps (an AdamW update is <= ~1 lr per step; a slice
+                              # that was zeroed, skipped or updated with a wrong gradient reads ~1 .. 1e3 here); measured worst 0.164 (layer 31 k_proj)
+UPDATE_FRAC_BAD = 0.09        # fraction of a tensor's elements whose two-step update differs by more than 0.5 lr (measured worst 0.071)
 
 
 def _avail_gb():
