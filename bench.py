@@ -349,21 +349,26 @@ def main():
     # only when they were taken on the kernel sources this run uses (radvlm_amd.build_id) and for the same workload -- else null
     headline = args.workload == "cxr" and args.batch == 32 and args.geometry == "llava15_7b" and not args.text_lens
 
-    def pmc(name):
-        try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                d = json.load(f)
-        except (OSError, ValueError):
-            return None
-        return d if (headline and d.get("kernel_source_sha256") == src_hash) else None
-    tr = pmc("r02_pmc_gemm_hbm_traffic.json")
+    def pmc(suffix):
+        """The newest profiles/rNN_<suffix> whose kernel-source hash is the one this run executes (else None)."""
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)), reverse=True):
+            try:
+                with open(path) as f:
+                    d = json.load(f)
+            except (OSError, ValueError):
+                continue
+            if headline and d.get("kernel_source_sha256") == src_hash:
+                return d, "profiles/" + os.path.basename(path)
+        return None, None
+    tr, tr_path = pmc("pmc_gemm_hbm_traffic.json")
     if tr:
         roofline["traffic"] = tr["gemm_kernel_256"]["hbm_bytes_per_launch"]
         roofline["traffic_over_algorithmic"] = roofline["traffic"] / roofline["algorithmic_bytes_per_launch"]
-        roofline["traffic_source"] = f"profiles/r02_pmc_gemm_hbm_traffic.json (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command, kernel sources {src_hash})"
+        roofline["traffic_source"] = f"{tr_path} (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command, kernel sources {src_hash})"
     else:
         roofline["traffic_source"] = f"null: no PMC pass on record for kernel sources {src_hash} / this workload"
-    mf = pmc("r02_pmc_mfma_util.json")
+    mf, _ = pmc("pmc_mfma_util.json")
     if mf:
         roofline["pmc_mfma"] = mf["gemm_kernel_256_all_forms"]
     tf_pair = TF_PER_PAIR.get(args.geometry) if args.workload == "cxr" else None
