@@ -222,6 +222,13 @@ int rv_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, v
 /* y += dropout(x) with the same mask as rv_dropout_bf16(p, seed): the adapter branch of a LoRA layer's input gradient,
  * dx += dropout'(dt A), in one pass (peft LoraLayer: lora_dropout is applied to the layer input, so its adjoint masks dt A). */
 int rv_dropout_add_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, void* stream);
+/* LoRA down-projection with the adapter's input dropout inside: T[M, R] = alpha / (1 - p) * mask(seed) o X[M, K] * A[R, K]^T
+ * = lora_A(lora_dropout(x)) * (alpha / r) of a peft LoraLayer (reference wiring train/train.py:1515-1532, defaults :152-157).
+ * The mask is that of rv_dropout_bf16(X as M * K contiguous elements, p, seed) -- backward re-creates dropout(X) with that call --
+ * and is applied to the operand fragments in registers: one pass over X instead of three.  X contiguous (ldx == K), K % 64 == 0,
+ * R <= 64, R % 4 == 0; p = 0: plain product. */
+int rv_lora_down_bf16(const void* X, int64_t ldx, const void* A, int64_t lda, void* T, int64_t ldt, int M, int R, int K, float alpha,
+                      float p, uint64_t seed, const void* zeros16, void* stream);
 /* torch.nn.GELU (erf) of the mm_projector (multimodal_projector/builder.py:44) and its derivative. */
 int rv_gelu_fwd(const void* x, void* y, int64_t n, void* stream);
 int rv_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);

@@ -65,4 +65,13 @@ DEVINL int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
+// Counter-based dropout mask (regenerable from (seed, element index): backward re-creates the forward's mask): element i of a tensor is
+// KEPT when rv_hash32(seed, i) >= p * 2^32.  splitmix64 finaliser, high word.
+DEVINL unsigned rv_hash32(unsigned long long seed, unsigned long long i) {
+    unsigned long long z = (i + seed * 0x9E3779B97F4A7C15ull) + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (unsigned)((z ^ (z >> 31)) >> 32);
+}
+
 static inline int rv_check_launch() { return hipGetLastError() == hipSuccess ? RV_OK : RV_ERR_LAUNCH; }

@@ -187,6 +187,82 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmParams P) {
 
 
 // ---------------------------------------------------------------------------------------------------------------
+// LoRA down-projection with the adapter's input dropout applied to the operand fragments:
+//     T[M, R] = alpha * dropout_p(X)[M, K] * A[R, K]^T            (peft LoraLayer: lora_A(lora_dropout(x)), train/train.py:1515-1532)
+// The unfused sequence wrote dropout(X) to HBM (read + write of X) and read it back in an R-wide GEMM -- three passes over X for a
+// product whose arithmetic is negligible (R = 64); here X is staged once (LDS-DMA), each lane masks the 8 elements of its A-operand
+// fragment with the SAME counter-based mask rv_dropout_bf16 uses (element index m * K + k: backward regenerates it with ops.dropout) and
+// the 1 / (1 - p) scale rides alpha.  HBM-bound: one pass over X.  64-row x 64-column x 64-deep tiles, 4 waves x 16 rows, 3-stage ring.
+constexpr int LD_BM = 64, LD_BN = 64, LD_STAGE = (LD_BM + LD_BN) * BK * 2, LD_NSTAGE = 3;
+struct LoraDownParams {
+    const bf16* X; const bf16* A; bf16* T; const bf16* zeros;
+    long ldx, lda, ldt;
+    int M, R, K;
+    float alpha;
+    unsigned thr; unsigned long long seed;      // keep element i when hash(seed, i) >= thr; thr = 0: no dropout
+};
+DEVINL void stage_rows64(const bf16* __restrict__ src, long ld, int row0, int nrows_total, int k0, const bf16* zeros, char* lds, int wid, int lane) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = (it * 4 + wid) * 64 + lane;   // 16-B chunk id in the 64 x 64 tile, 0..511
+        const int r = c >> 3, p = c & 7;
+        const int lc = p ^ ((r >> 1) & 7);
+        const int gr = row0 + r;
+        const bf16* g = gr < nrows_total ? (src + (long)gr * ld + k0 + lc * 8) : zeros;
+        glds16(g, lds + (it * 4 + wid) * 1024);
+    }
+}
+__global__ __launch_bounds__(256, 3) void lora_down_kernel(LoraDownParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wid = wave_id(), lane = lane_id();
+    const int m0 = blockIdx.x * LD_BM;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nt = P.K / BK;
+    auto stage = [&](int t) {
+        char* dst = smem + (t % LD_NSTAGE) * LD_STAGE;
+        stage_rows64(P.X, P.ldx, m0, P.M, t * BK, P.zeros, dst, wid, lane);
+        stage_rows64(P.A, P.lda, 0, P.R, t * BK, P.zeros, dst + LD_BM * BK * 2, wid, lane);
+    };
+    stage(0);
+    if (nt > 1) stage(1);
+    const int row = wid * 16 + (lane & 15);                  // this lane's X row within the tile
+    const unsigned long long ebase = (unsigned long long)(m0 + row) * (unsigned long long)P.K + (unsigned long long)((lane >> 4) * 8);
+    for (int t = 0; t < nt; ++t) {
+        // tile t was issued two steps ago: all but the 4 pieces of tile t + 1 must have landed
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 2 < nt) stage(t + 2);                        // its slot was read in step t - 1 (every wave is past that barrier)
+        const char* At = smem + (t % LD_NSTAGE) * LD_STAGE;
+        const char* Bt = At + LD_BM * BK * 2;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int kc = kk * 4 + (lane >> 4);
+            bf16x8 a = read_frag(At, row, kc);
+            if (P.thr) {
+                const unsigned long long e = ebase + (unsigned long long)(t * BK + kk * 32);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = rv_hash32(P.seed, e + j) >= P.thr ? a[j] : (bf16)0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = mfma16(read_frag(Bt, j * 16 + (lane & 15), kc), a, acc[j]);
+        }
+    }
+    // lane holds T[m0 + 16 wid + (lane & 15)][16 j + 4 (lane >> 4) + r]
+    const int m = m0 + row;
+    if (m >= P.M) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = j * 16 + 4 * (lane >> 4);
+        if (n >= P.R) continue;
+        bf16* tp = P.T + (long)m * P.ldt + n;
+        *(bf16x4*)tp = bf16x4{f2bf(acc[j][0] * P.alpha), f2bf(acc[j][1] * P.alpha), f2bf(acc[j][2] * P.alpha), f2bf(acc[j][3] * P.alpha)};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // v2: 256x256x64 block tile, 8 waves (2 M x 4 N), 128x64 per wave, 1 block/CU (all 160 KiB of LDS, <=256 VGPR).
 // Each K-tile is staged as four 16-KiB half-tiles (A rows 0-127 / 128-255, B rows 0-127 / 128-255), ONE half-tile per
 // phase, into a 3-deep A ring + 2-deep B ring (10 slots); a K-tile is computed in four phases of 16 MFMAs (one 64x32
@@ -1342,4 +1418,24 @@ extern "C" int rv_gemm_swiglu_bwd_bf16(const void* dY, int64_t ldy, const void* 
     P.lda = ldy; P.ldb = ldw; P.ldc = lddgu; P.M = M; P.N = F; P.K = K; P.alpha = 1.f;
     P.F = F; P.G = (const bf16*)GU; P.ldg = ldgu;
     return launch_fused<EPI_SWIGLU_BWD, true>(P, (M + BM2 - 1) / BM2, (F + BN2 - 1) / BN2, (hipStream_t)stream);
+}
+
+// T[M, R] = alpha / (1 - p) * dropout_p(X)[M, K] A[R, K]^T with the mask of rv_dropout_bf16(X viewed as M * K contiguous elements, p, seed):
+// the LoRA adapters' down-projection (peft LoraLayer: lora_A(lora_dropout(x)), reference wiring train/train.py:1515-1532) in ONE pass over X.
+extern "C" int rv_lora_down_bf16(const void* X, int64_t ldx, const void* A, int64_t lda, void* T, int64_t ldt, int M, int R, int K, float alpha,
+                                 float p, uint64_t seed, const void* zeros16, void* stream) {
+    if (!X || !A || !T || !zeros16 || M <= 0 || R <= 0 || K <= 0 || p < 0.f || p >= 1.f) return RV_ERR_ARG;
+    // the mask indexes X as a contiguous [M, K] tensor (ldx == K), like the dropout kernels backward re-creates it with
+    if (R > LD_BN || (R & 3) || (K % BK) || ldx != K || (lda & 7) || (ldt & 3)) return RV_ERR_ARG;
+    if ((((uintptr_t)X) | ((uintptr_t)A) | ((uintptr_t)zeros16)) & 15) return RV_ERR_ARG;
+    if (((uintptr_t)T) & 7) return RV_ERR_ARG;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)lora_down_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LD_NSTAGE * LD_STAGE); attr = true; }
+    LoraDownParams P;
+    P.X = (const bf16*)X; P.A = (const bf16*)A; P.T = (bf16*)T; P.zeros = (const bf16*)zeros16;
+    P.ldx = ldx; P.lda = lda; P.ldt = ldt; P.M = M; P.R = R; P.K = K;
+    P.alpha = p > 0.f ? alpha / (1.f - p) : alpha;
+    P.thr = (unsigned)((double)p * 4294967296.0); P.seed = seed;
+    hipLaunchKernelGGL(lora_down_kernel, dim3((M + LD_BM - 1) / LD_BM), dim3(256), LD_NSTAGE * LD_STAGE, (hipStream_t)stream, P);
+    return rv_check_launch();
 }

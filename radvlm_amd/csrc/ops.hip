@@ -345,12 +345,7 @@ __global__ void swiglu_bwd_kernel(const bf16* dact, long ld_dact, const bf16* gu
     st8(dgu + r * ld_dgu + F + f, du);
 }
 
-DEVINL unsigned hash32(unsigned long long seed, unsigned long long i) {
-    unsigned long long z = (i + seed * 0x9E3779B97F4A7C15ull) + 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return (unsigned)((z ^ (z >> 31)) >> 32);
-}
+DEVINL unsigned hash32(unsigned long long seed, unsigned long long i) { return rv_hash32(seed, i); }   // common.h: shared with rv_lora_down_bf16
 __global__ void dropout_kernel(const bf16* x, bf16* y, long n8, unsigned thr, float scale, unsigned long long seed) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n8) return;

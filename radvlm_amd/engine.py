@@ -721,8 +721,8 @@ class LlavaEngine:
         for lname, c0, c1 in mods:
             pre = f"model.layers.{i}.{lname}."
             A, B = self.W(pre + "lora_A.weight"), self.W(pre + "lora_B.weight")
-            xd = ops.dropout(x, self.lora_p, self._lora_seed(i, lname)) if self.lora_p > 0 else x
-            t = ops.gemm(xd, A, alpha=self.lora_scale)
+            # t = (alpha / r) * dropout(x) A^T: one pass over x, the mask applied to the operand fragments (rv_lora_down_bf16)
+            t = ops.lora_down(x, A, self.lora_scale, self.lora_p, self._lora_seed(i, lname))
             ops.gemm(x, w[c0:c1], out=y[:, c0:c1], bias=None if bias is None else bias[c0:c1],
                      residual=None if residual is None else residual[:, c0:c1], a2=t, b2=B)
             saved[lname] = t

@@ -367,6 +367,19 @@ def dropout(x, p, seed, y=None):
     return y
 
 
+def lora_down(x, a, alpha, p, seed, out=None):
+    """t[M, r] = alpha * dropout_p(x) @ a^T with the mask of dropout(x, p, seed), in one pass over x (x contiguous [M, K], K % 64 == 0,
+    r <= 64); other shapes take the two-launch sequence."""
+    M, K = x.shape
+    r = a.shape[0]
+    if not (x.is_contiguous() and K % 64 == 0 and r <= 64 and r % 4 == 0 and a.stride(1) == 1):
+        return gemm(dropout(x.contiguous(), p, seed) if p > 0 else x, a, alpha=alpha, out=out)
+    if out is None:
+        out = torch.empty(M, r, dtype=BF16, device=x.device)
+    lib.call("rv_lora_down_bf16", x, K, a, a.stride(0), out, out.stride(0), M, r, K, float(alpha), float(p), int(seed), lib.zeros16(x.device))
+    return out
+
+
 def dropout_add(x, y, p, seed):
     """y += dropout(x) (same regenerable mask as dropout(x, p, seed)), one pass."""
     assert x.is_contiguous() and y.is_contiguous() and x.shape == y.shape

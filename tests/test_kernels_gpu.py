@@ -727,3 +727,25 @@ def test_flat_buffer_kernels_beyond_2_32_elements(ops):
     torch.cuda.synchronize()
     for i in (0, n // 2, n - 1):
         assert abs(float(p[i]) + 0.5) < 1e-3 and abs(float(f[i]) + 0.5) < 1e-3, i
+
+
+@pytest.mark.parametrize("M,K,R,p", [(200, 128, 64, 0.25), (64, 64, 64, 0.5), (1000, 5120, 64, 0.05), (333, 256, 16, 0.0), (129, 192, 8, 0.1)])
+def test_lora_down_projection_with_dropout_inside(ops, M, K, R, p):
+    """rv_lora_down_bf16: t = alpha * dropout_p(x) A^T in one pass over x, the mask applied to the operand fragments -- against the two-launch
+    sequence it replaces (rv_dropout_bf16 then rv_gemm_bf16) and, through an identity adapter, element by element against the mask of
+    rv_dropout_bf16 itself (backward re-creates dropout(x) with that call: peft LoraLayer semantics, reference train/train.py:1515-1532)."""
+    x, a = rnd(310, (M, K), 1.0).cuda(), rnd(311, (R, K), 0.2).cuda()
+    seed, alpha = 4242, 0.25
+    got = ops.lora_down(x, a, alpha, p, seed)
+    xd = ops.dropout(x, p, seed) if p > 0 else x
+    want = ops.gemm(xd, a, alpha=alpha, out_dtype=torch.float32)
+    assert got.shape == (M, R) and relerr(got.float().cpu(), want.cpu()) < TOL
+    if K == 64 and R == 64:
+        eye = torch.eye(64, dtype=torch.bfloat16, device="cuda")
+        t = ops.lora_down(x, eye, 1.0, p, seed)
+        kept = ops.dropout(x, p, seed) != 0
+        assert torch.equal((t != 0) | (x == 0), kept | (x == 0))               # the same mask, element for element
+        assert relerr(t[kept].float().cpu(), (x[kept].float() / (1 - p)).cpu()) < TOL
+    # non-contiguous x takes the two-launch sequence
+    wide = torch.cat((x, x), 1)
+    assert relerr(ops.lora_down(wide[:, :K], a, alpha, p, seed).float().cpu(), want.cpu()) < TOL
