@@ -216,7 +216,8 @@ int rv_rope_inplace_pos(void* x, int64_t ld, const float* cos_sin, const int32_t
 int rv_swiglu_fwd(const void* gu, int64_t ld_gu, void* act, int64_t ld_act, int rows, int F, void* stream);
 int rv_swiglu_bwd(const void* dact, int64_t ld_dact, const void* gu, int64_t ld_gu, void* dgu, int64_t ld_dgu, int rows,
                   int F, void* stream);
-/* Inverted dropout with a counter-based mask: y[i] = keep(seed, i) ? x[i] / (1 - p) : 0, keep = hash(seed, i) >= p.
+/* Inverted dropout with a counter-based mask: y[i] = keep(seed, i) ? x[i] / (1 - p) : 0; keep: 16 bits of a splitmix64 value shared by the
+ * four elements i >> 2, compared with round(p * 2^16) (p is honoured to 1.5e-5).
  * The same (seed, p) regenerates the mask, so backward applies the same call to the gradient (lora_dropout). */
 int rv_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, void* stream);
 /* y += dropout(x) with the same mask as rv_dropout_bf16(p, seed): the adapter branch of a LoRA layer's input gradient,

@@ -65,13 +65,26 @@ DEVINL int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-// Counter-based dropout mask (regenerable from (seed, element index): backward re-creates the forward's mask): element i of a tensor is
-// KEPT when rv_hash32(seed, i) >= p * 2^32.  splitmix64 finaliser, high word.
-DEVINL unsigned rv_hash32(unsigned long long seed, unsigned long long i) {
-    unsigned long long z = (i + seed * 0x9E3779B97F4A7C15ull) + 0x9E3779B97F4A7C15ull;
+// Counter-based dropout mask (regenerable from (seed, element index): backward re-creates the forward's mask).  One splitmix64 value
+// serves FOUR consecutive elements, 16 bits each: element i is KEPT when bits [16 (i & 3), +16) of hash(seed, i >> 2) are >= round(p * 2^16).
+// (A hash per element made the mask generation, not HBM, the bound of every kernel that applies it inside another pass.)
+DEVINL unsigned long long rv_hash64(unsigned long long seed, unsigned long long b) {
+    unsigned long long z = (b + seed * 0x9E3779B97F4A7C15ull) + 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return (unsigned)((z ^ (z >> 31)) >> 32);
+    return z ^ (z >> 31);
 }
+// keep flags of the 8 consecutive elements e0 .. e0 + 7 (e0 % 8 == 0) as the low 8 bits
+DEVINL unsigned rv_keep8(unsigned long long seed, unsigned long long e0, unsigned thr16) {
+    const unsigned long long h0 = rv_hash64(seed, e0 >> 2), h1 = rv_hash64(seed, (e0 >> 2) + 1);
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        m |= (((unsigned)(h0 >> (16 * j)) & 0xFFFFu) >= thr16 ? 1u : 0u) << j;
+        m |= (((unsigned)(h1 >> (16 * j)) & 0xFFFFu) >= thr16 ? 1u : 0u) << (4 + j);
+    }
+    return m;
+}
+static inline unsigned rv_dropout_thr16(float p) { return (unsigned)((double)p * 65536.0 + 0.5); }
 
 static inline int rv_check_launch() { return hipGetLastError() == hipSuccess ? RV_OK : RV_ERR_LAUNCH; }

@@ -199,7 +199,7 @@ struct LoraDownParams {
     long ldx, lda, ldt;
     int M, R, K;
     float alpha;
-    unsigned thr; unsigned long long seed;      // keep element i when hash(seed, i) >= thr; thr = 0: no dropout
+    unsigned thr; unsigned long long seed;      // 16-bit keep threshold of the shared mask (common.h, rv_keep8); thr = 0: no dropout
 };
 DEVINL void stage_rows64(const bf16* __restrict__ src, long ld, int row0, int nrows_total, int k0, const bf16* zeros, char* lds, int wid, int lane) {
 #pragma unroll
@@ -242,9 +242,9 @@ __global__ __launch_bounds__(256, 3) void lora_down_kernel(LoraDownParams P) {
             const int kc = kk * 4 + (lane >> 4);
             bf16x8 a = read_frag(At, row, kc);
             if (P.thr) {
-                const unsigned long long e = ebase + (unsigned long long)(t * BK + kk * 32);
+                const unsigned keep = rv_keep8(P.seed, ebase + (unsigned long long)(t * BK + kk * 32), P.thr);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) a[j] = rv_hash32(P.seed, e + j) >= P.thr ? a[j] : (bf16)0.f;
+                for (int j = 0; j < 8; ++j) a[j] = (keep >> j) & 1 ? a[j] : (bf16)0.f;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = mfma16(read_frag(Bt, j * 16 + (lane & 15), kc), a, acc[j]);
@@ -1435,7 +1435,7 @@ extern "C" int rv_lora_down_bf16(const void* X, int64_t ldx, const void* A, int6
     P.X = (const bf16*)X; P.A = (const bf16*)A; P.T = (bf16*)T; P.zeros = (const bf16*)zeros16;
     P.ldx = ldx; P.lda = lda; P.ldt = ldt; P.M = M; P.R = R; P.K = K;
     P.alpha = p > 0.f ? alpha / (1.f - p) : alpha;
-    P.thr = (unsigned)((double)p * 4294967296.0); P.seed = seed;
+    P.thr = rv_dropout_thr16(p); P.seed = seed;
     hipLaunchKernelGGL(lora_down_kernel, dim3((M + LD_BM - 1) / LD_BM), dim3(256), LD_NSTAGE * LD_STAGE, (hipStream_t)stream, P);
     return rv_check_launch();
 }

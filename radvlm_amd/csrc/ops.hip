@@ -345,25 +345,26 @@ __global__ void swiglu_bwd_kernel(const bf16* dact, long ld_dact, const bf16* gu
     st8(dgu + r * ld_dgu + F + f, du);
 }
 
-DEVINL unsigned hash32(unsigned long long seed, unsigned long long i) { return rv_hash32(seed, i); }   // common.h: shared with rv_lora_down_bf16
-__global__ void dropout_kernel(const bf16* x, bf16* y, long n8, unsigned thr, float scale, unsigned long long seed) {
+__global__ void dropout_kernel(const bf16* x, bf16* y, long n8, unsigned thr16, float scale, unsigned long long seed) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n8) return;
     float v[8], o[8];
     ld8(x + i * 8, v);
+    const unsigned keep = rv_keep8(seed, (unsigned long long)i * 8, thr16);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = hash32(seed, (unsigned long long)(i * 8 + j)) >= thr ? v[j] * scale : 0.f;
+    for (int j = 0; j < 8; ++j) o[j] = (keep >> j) & 1 ? v[j] * scale : 0.f;
     st8(y + i * 8, o);
 }
 
-__global__ void dropout_add_kernel(const bf16* x, bf16* y, long n8, unsigned thr, float scale, unsigned long long seed) {
+__global__ void dropout_add_kernel(const bf16* x, bf16* y, long n8, unsigned thr16, float scale, unsigned long long seed) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n8) return;
     float v[8], o[8];
     ld8(x + i * 8, v);
     ld8(y + i * 8, o);
+    const unsigned keep = rv_keep8(seed, (unsigned long long)i * 8, thr16);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] += hash32(seed, (unsigned long long)(i * 8 + j)) >= thr ? v[j] * scale : 0.f;
+    for (int j = 0; j < 8; ++j) o[j] += (keep >> j) & 1 ? v[j] * scale : 0.f;
     st8(y + i * 8, o);
 }
 
@@ -858,14 +859,12 @@ extern "C" int rv_swiglu_bwd(const void* dact, int64_t ld_dact, const void* gu, 
 }
 extern "C" int rv_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, void* stream) {
     if (!x || !y || n <= 0 || (n & 7) || p < 0.f || p >= 1.f) return RV_ERR_ARG;
-    const unsigned thr = (unsigned)((double)p * 4294967296.0);
-    hipLaunchKernelGGL(dropout_kernel, dim3(nblocks(n / 8, 256)), dim3(256), 0, ST, (const bf16*)x, (bf16*)y, (long)(n / 8), thr, 1.f / (1.f - p), (unsigned long long)seed);
+    hipLaunchKernelGGL(dropout_kernel, dim3(nblocks(n / 8, 256)), dim3(256), 0, ST, (const bf16*)x, (bf16*)y, (long)(n / 8), rv_dropout_thr16(p), 1.f / (1.f - p), (unsigned long long)seed);
     return rv_check_launch();
 }
 extern "C" int rv_dropout_add_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, void* stream) {
     if (!x || !y || n <= 0 || (n & 7) || p < 0.f || p >= 1.f) return RV_ERR_ARG;
-    const unsigned thr = (unsigned)((double)p * 4294967296.0);
-    hipLaunchKernelGGL(dropout_add_kernel, dim3(nblocks(n / 8, 256)), dim3(256), 0, ST, (const bf16*)x, (bf16*)y, (long)(n / 8), thr, 1.f / (1.f - p), (unsigned long long)seed);
+    hipLaunchKernelGGL(dropout_add_kernel, dim3(nblocks(n / 8, 256)), dim3(256), 0, ST, (const bf16*)x, (bf16*)y, (long)(n / 8), rv_dropout_thr16(p), 1.f / (1.f - p), (unsigned long long)seed);
     return rv_check_launch();
 }
 extern "C" int rv_gelu_fwd(const void* x, void* y, int64_t n, void* stream) {
