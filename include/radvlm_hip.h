@@ -228,6 +228,11 @@ int rv_dropout_add_bf16(const void* x, void* y, int64_t n, float p, uint64_t see
  * The mask is that of rv_dropout_bf16(X as M * K contiguous elements, p, seed) -- backward re-creates dropout(X) with that call --
  * and is applied to the operand fragments in registers: one pass over X instead of three.  X contiguous (ldx == K), K % 64 == 0,
  * R <= 64, R % 4 == 0; p = 0: plain product. */
+/* dx[M, N] (+)= dropout'(alpha * dT[M, K] op(A)): the adapter branch of a LoRA layer's input gradient with the forward's dropout mask
+ * (that of rv_dropout_bf16 over M * N elements) applied to the accumulators in the GEMM epilogue.  trans_b: A stored [K, N] (lora_A [r, in]).
+ * accumulate != 0: added to dx.  N % 8 == 0. */
+int rv_gemm_dropout_add_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K, int trans_b,
+                             float alpha, float p, uint64_t seed, int accumulate, const void* zeros16, void* stream);
 int rv_lora_down_bf16(const void* X, int64_t ldx, const void* A, int64_t lda, void* T, int64_t ldt, int M, int R, int K, float alpha,
                       float p, uint64_t seed, const void* zeros16, void* stream);
 /* torch.nn.GELU (erf) of the mm_projector (multimodal_projector/builder.py:44) and its derivative. */

@@ -44,6 +44,9 @@ struct GemmParams {
     int F; bf16* C2; long ldc2; const bf16* G; long ldg;
     unsigned bytesA, bytesB;     // BUF kernels: extent of each operand = its buffer resource's num_records
     unsigned bytesA2, bytesB2;   // BUF + MODE 1: the second operand pair's extents
+    // dropout on the product (general epilogue of the 256x256 kernel): C = residual + keep(seed, m * N + n) ? alpha * acc / (1 - p) : 0 -- the
+    // adapter branch of a LoRA layer's input gradient (rv_gemm_dropout_add_bf16); drop_thr = 0: off
+    unsigned drop_thr; float drop_scale; unsigned long long drop_seed;
 };
 enum { EPI_NONE = 0, EPI_ROPE = 1, EPI_SWIGLU_FWD = 2, EPI_SWIGLU_BWD = 3 };
 
@@ -645,7 +648,7 @@ DEVINL void epilogue_256(const f32x4 (&acc)[8][4], const GemmParams& P, int m0, 
 #ifndef RV_NO_COMPACT_EPILOGUE
     // the common case (plain bf16 product: every dgrad / wgrad-free forward GEMM of the decoder) gets a compact instruction stream:
     // the general path below is ~20k instructions of mostly untaken branches per kernel, fetched once per tile
-    if (MODE == 0 && !P.bias && P.act == RV_ACT_NONE && !P.R && !P.out_f32 && P.alpha == 1.f && n_vec_ok) {
+    if (MODE == 0 && !P.bias && P.act == RV_ACT_NONE && !P.R && !P.out_f32 && P.alpha == 1.f && n_vec_ok && !P.drop_thr) {
         static_for<16>([&](auto ia) {
             constexpr int i = decltype(ia)::value >> 1, a = decltype(ia)::value & 1;
             const int m = m0 + wr * 128 + i * 16 + (lane & 15);
@@ -687,6 +690,11 @@ DEVINL void epilogue_256(const f32x4 (&acc)[8][4], const GemmParams& P, int m0, 
         if (P.act != RV_ACT_NONE) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] = apply_act(v[r], P.act);
+        }
+        if (P.drop_thr) {        // N % 8 == 0 (checked on the host): the 8 columns are one mask word
+            const unsigned keep = rv_keep8(P.drop_seed, (unsigned long long)m * (unsigned long long)P.N + (unsigned long long)n, P.drop_thr);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = (keep >> r) & 1 ? v[r] * P.drop_scale : 0.f;
         }
         if (P.R) {
             if (P.res_f32) {
@@ -1245,10 +1253,10 @@ static void launch256(GemmParams& P, int mode, hipStream_t st) {
     else launch256m<TA, TB, 0>(P, st);
 }
 
-extern "C" int rv_gemm_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
-                               const void* residual, int64_t ldr, int M, int N, int K, int trans_a, int trans_b, float alpha,
-                               int act, int out_f32, int res_f32, const void* A2, int64_t lda2, const void* B2, int64_t ldb2,
-                               int K2, void* workspace, int64_t workspace_bytes, const void* zeros16, void* stream) {
+static int gemm_ex_impl(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
+                        const void* residual, int64_t ldr, int M, int N, int K, int trans_a, int trans_b, float alpha,
+                        int act, int out_f32, int res_f32, const void* A2, int64_t lda2, const void* B2, int64_t ldb2,
+                        int K2, void* workspace, int64_t workspace_bytes, const void* zeros16, void* stream, float drop_p, uint64_t drop_seed) {
     if (!A || !B || !C || !zeros16 || M <= 0 || N <= 0 || K <= 0) return RV_ERR_ARG;
     if ((lda & 7) || (ldb & 7)) return RV_ERR_ARG;
     if ((!trans_a && (K & 7)) || (trans_a && (M & 7)) || (!trans_b && (K & 7)) || (trans_b && (N & 7))) return RV_ERR_ARG;
@@ -1262,6 +1270,8 @@ extern "C" int rv_gemm_bf16_ex(const void* A, int64_t lda, const void* B, int64_
     P.M = M; P.N = N; P.K = K; P.act = act; P.out_f32 = out_f32; P.res_f32 = res_f32; P.alpha = alpha;
     P.A2 = (const bf16*)A2; P.B2 = (const bf16*)B2; P.lda2 = lda2; P.ldb2 = ldb2; P.K2 = ext ? K2 : 0;
     P.ws = (float*)workspace; P.splits = 1;
+    P.drop_thr = drop_p > 0.f ? rv_dropout_thr16(drop_p) : 0u; P.drop_scale = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f; P.drop_seed = drop_seed;
+    const bool dropping = P.drop_thr != 0;       // lives in the general epilogue of the 256x256 whole-tile kernel only
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NSTAGE * STAGE_BYTES);
@@ -1275,6 +1285,7 @@ extern "C" int rv_gemm_bf16_ex(const void* A, int64_t lda, const void* B, int64_
     const int cus = cu_budget();            // 256 on an idle MI355X; fewer when collectives are planned to run beside the GEMMs
     // split-K: few output tiles but a long contraction (LoRA / bias-like gradients): spread K over the idle CUs
     int mode = ext ? 1 : 0;
+    if (dropping) workspace = nullptr;           // no K-split shapes: their reduce kernels do not carry the mask
     if (!ext && workspace && tiles256 <= cus / 4 && nt >= 16) {
         int sp = (int)(cus / tiles256);
         if (sp > nt / 4) sp = nt / 4;
@@ -1299,7 +1310,7 @@ extern "C" int rv_gemm_bf16_ex(const void* A, int64_t lda, const void* B, int64_
     const long tiles128 = (long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const double cost256 = 4.0 * (double)((tiles256 + cus - 1) / cus);
     const double cost128 = 2.0 * 1.15 * (double)((tiles128 + 2 * cus - 1) / (2 * cus));
-    const bool use256 = (trans_a || trans_b || mode) ? true : (force ? (force == 2) : (cost256 <= cost128));
+    const bool use256 = (trans_a || trans_b || mode || dropping) ? true : (force ? (force == 2) : (cost256 <= cost128));
     hipStream_t st = (hipStream_t)stream;
     if (use256) {
 #ifdef RV_STAMPS
@@ -1313,6 +1324,25 @@ extern "C" int rv_gemm_bf16_ex(const void* A, int64_t lda, const void* B, int64_
         hipLaunchKernelGGL(gemm_nt_kernel, dim3(P.tiles_m * P.tiles_n), dim3(256), NSTAGE * STAGE_BYTES, st, P);
     }
     return rv_check_launch();
+}
+
+extern "C" int rv_gemm_bf16_ex(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,
+                               const void* residual, int64_t ldr, int M, int N, int K, int trans_a, int trans_b, float alpha,
+                               int act, int out_f32, int res_f32, const void* A2, int64_t lda2, const void* B2, int64_t ldb2,
+                               int K2, void* workspace, int64_t workspace_bytes, const void* zeros16, void* stream) {
+    return gemm_ex_impl(A, lda, B, ldb, C, ldc, bias, residual, ldr, M, N, K, trans_a, trans_b, alpha, act, out_f32, res_f32, A2, lda2, B2, ldb2, K2,
+                        workspace, workspace_bytes, zeros16, stream, 0.f, 0);
+}
+
+// C[M, N] (+)= dropout_p(alpha * A[M, K] op(B)) with the mask of rv_dropout_bf16 over the M * N elements of the product: the adapter branch of
+// a LoRA layer's input gradient, dx += dropout'(dt A) (peft LoraLayer: lora_dropout acts on the layer input, so its adjoint masks dt A with
+// the forward's mask; reference wiring train/train.py:1515-1532).  The mask is applied to the accumulators in the epilogue: the product
+// never reaches HBM unmasked (the unfused sequence wrote it, read it back and read + wrote dx).  accumulate != 0: C = C + ...; N % 8 == 0.
+extern "C" int rv_gemm_dropout_add_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, int M, int N, int K,
+                                        int trans_b, float alpha, float p, uint64_t seed, int accumulate, const void* zeros16, void* stream) {
+    if (p < 0.f || p >= 1.f || (N & 7) || (ldc & 7) || (((uintptr_t)C) & 15)) return RV_ERR_ARG;
+    return gemm_ex_impl(A, lda, B, ldb, C, ldc, nullptr, accumulate ? C : nullptr, ldc, M, N, K, 0, trans_b, alpha, RV_ACT_NONE, 0, 0, nullptr, 0,
+                        nullptr, 0, 0, nullptr, 0, zeros16, stream, p, seed);
 }
 
 extern "C" int rv_gemm_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* bias,

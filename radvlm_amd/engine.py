@@ -754,7 +754,7 @@ class LlavaEngine:
                 ops.gemm(dts, ops.dropout(x, self.lora_p, seed), ta=True, tb=True, out=gA, residual=gA if acc else None, workspace=ws)
                 if not base_done:
                     ops.gemm(dyj, w[c0:c1], tb=True, out=dx, residual=None if first else dx)
-                ops.dropout_add(ops.gemm(dts, A, tb=True), dx, self.lora_p, seed)   # dx += dropout'(dts A), one pass
+                ops.gemm_dropout_add(dts, A, dx, self.lora_p, seed)   # dx += dropout'(dts A): the mask is applied in the GEMM epilogue
             else:
                 ops.gemm(dts, x, ta=True, tb=True, out=gA, residual=gA if acc else None, workspace=ws)
                 ops.gemm(dyj, w[c0:c1], tb=True, out=dx, residual=None if first else dx, a2=dts, b2=A)

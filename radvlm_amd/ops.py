@@ -380,6 +380,21 @@ def lora_down(x, a, alpha, p, seed, out=None):
     return out
 
 
+def gemm_dropout_add(a, b, y, p, seed, tb=True, alpha=1.0, accumulate=True):
+    """y (+)= dropout(alpha * a @ op(b)) with the mask of dropout(., p, seed) over y's elements, applied in the GEMM epilogue (the product is
+    never stored unmasked).  a [M, K], b [K, N] (tb) or [N, K]; y [M, N] contiguous rows."""
+    _chk(a), _chk(b), _chk(y)
+    M, K = a.shape
+    N = b.shape[1] if tb else b.shape[0]
+    assert y.shape == (M, N) and (b.shape[0] if tb else b.shape[1]) == K and a.stride(1) == 1 and b.stride(1) == 1 and y.stride(1) == 1
+    if p <= 0 or N % 8 or y.stride(0) != N:       # the mask indexes y as M * N contiguous elements
+        t = gemm(a, b, tb=tb, alpha=alpha)
+        return dropout_add(t, y, p, seed) if p > 0 else y.add_(t) if accumulate else y.copy_(t)
+    lib.call("rv_gemm_dropout_add_bf16", a, a.stride(0), b, b.stride(0), y, y.stride(0), M, N, K, int(tb), float(alpha), float(p), int(seed),
+             int(accumulate), lib.zeros16(a.device))
+    return y
+
+
 def dropout_add(x, y, p, seed):
     """y += dropout(x) (same regenerable mask as dropout(x, p, seed)), one pass."""
     assert x.is_contiguous() and y.is_contiguous() and x.shape == y.shape

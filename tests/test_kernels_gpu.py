@@ -749,3 +749,19 @@ def test_lora_down_projection_with_dropout_inside(ops, M, K, R, p):
     # non-contiguous x takes the two-launch sequence
     wide = torch.cat((x, x), 1)
     assert relerr(ops.lora_down(wide[:, :K], a, alpha, p, seed).float().cpu(), want.cpu()) < TOL
+
+
+@pytest.mark.parametrize("M,N,K,p", [(300, 256, 64, 0.25), (1000, 5120, 64, 0.05), (256, 512, 128, 0.5), (64, 72, 64, 0.1)])
+def test_gemm_with_dropout_in_the_epilogue(ops, M, N, K, p):
+    """rv_gemm_dropout_add_bf16: y += dropout(dt @ A) with the mask applied to the accumulators (the adapter branch of a LoRA layer's input
+    gradient) against the sequence it replaces -- rv_gemm_bf16 then rv_dropout_add_bf16 -- and the mask itself element for element."""
+    dt, a, y = rnd(320, (M, K), 1.0).cuda(), rnd(321, (K, N), 0.5).cuda(), rnd(322, (M, N), 1.0).cuda()
+    seed = 991
+    want = ops.dropout_add(ops.gemm(dt, a, tb=True), y.clone(), p, seed)
+    got = ops.gemm_dropout_add(dt, a, y.clone(), p, seed)
+    assert relerr(got.float().cpu(), want.float().cpu()) < TOL
+    prod = ops.gemm(dt, a, tb=True)
+    kept = ops.dropout(prod, p, seed) != 0
+    assert torch.equal(got[~kept & (prod != 0)], y[~kept & (prod != 0)])           # dropped positions are untouched
+    fresh = ops.gemm_dropout_add(dt, a, torch.full_like(y, 7.0), p, seed, accumulate=False)
+    assert relerr(fresh.float().cpu(), ops.dropout(prod, p, seed).float().cpu()) < TOL

@@ -14,7 +14,7 @@ FAMILIES = [("gemm_kernel_256", "GEMM 256x256 (all forms)"), ("gemm_nt_kernel", 
             ("splitk_reduce", "GEMM split-K reduce"), ("attn_fwd_nat", "attention fwd (hd 128)"), ("attn_bwd_dq_nat", "attention bwd dQ"),
             ("attn_bwd_dkv_nat", "attention bwd dK/dV"), ("attn_fwd_kernel", "tower attention fwd (hd 64)"), ("attn_bwd_", "tower attention bwd"),
             ("adamw", "AdamW"), ("rmsnorm", "RMSNorm fwd+bwd"), ("layernorm", "LayerNorm"), ("colsum", "column sums"), ("sumsq", "grad norm"),
-            ("cross_entropy", "cross entropy"), ("dropout", "dropout (LoRA)"), ("swiglu", "SwiGLU (unfused)"), ("rope", "RoPE (unfused)"),
+            ("cross_entropy", "cross entropy"), ("lora_down", "LoRA down-projection (dropout inside)"), ("dropout", "dropout (LoRA)"), ("swiglu", "SwiGLU (unfused)"), ("rope", "RoPE (unfused)"),
             ("group_sum_heads", "GQA group sum")]
 STARTUP = ("distribution_elementwise", "bfloat16_copy", "cast_bf16_f32", "copyBuffer", "FillFunctor<float>")
 
@@ -34,9 +34,11 @@ def main():
                 fam[label] = fam.get(label, 0.0) + ms
                 break
         else:
-            other[re.sub(r"\(.*", "", name)[:60]] = ms
+            key = re.sub(r"\(anonymous namespace\)::|void |\(.*", "", name.replace("(anonymous namespace)::", ""))[:60] or name[:60]
+            other[key] = other.get(key, 0.0) + ms
     out = {"source": path, "steps_in_trace": steps, "ms_per_step": {k: round(v / steps, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
-           "other_ms_per_step": round(sum(other.values()) / steps, 3), "startup_ms_total": round(startup, 2)}
+           "other_ms_per_step": round(sum(other.values()) / steps, 3),
+           "other_largest": {k: round(v / steps, 3) for k, v in sorted(other.items(), key=lambda kv: -kv[1])[:6]}, "startup_ms_total": round(startup, 2)}
     out["sum_ms_per_step"] = round(sum(out["ms_per_step"].values()) + out["other_ms_per_step"], 2)
     gemm = sum(v for k, v in out["ms_per_step"].items() if k.startswith("GEMM"))
     out["gemm_ms_per_step"] = round(gemm, 2)
