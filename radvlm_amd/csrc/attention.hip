@@ -105,6 +105,15 @@ DEVINL bf16x8 pack8(f32x4 a, f32x4 b) {
     return bf16x8{f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
 }
 DEVINL float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#ifdef RV_ATTN_STAMPS
+// Diagnostic build only (tools/attn_stamps.py): per-wave cycle accumulators of the forward kernel's tile phases -> P.delta (unused by the
+// forward), viewed as long long [blocks][4 waves][6]: wait + barrier, K reads + score MFMAs, softmax, P V, tiles, whole kernel.
+#define ATT_T0() long long att_t = __builtin_readcyclecounter()
+#define ATT_ACC(k) do { asm volatile("" ::: "memory"); const long long n_ = __builtin_readcyclecounter(); att_dbg[k] += n_ - att_t; att_t = n_; } while (0)
+#else
+#define ATT_T0() do { } while (0)
+#define ATT_ACC(k) do { } while (0)
+#endif
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
@@ -450,24 +459,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
     plV.stage(rsV, hoff, smem + TILE, wid);
     NatAddr ad;
     ad.init(smem + STAGE, lane);          // the first tile's toggle brings it to stage 0
+#ifdef RV_ATTN_STAMPS
+    long long att_dbg[6] = {0, 0, 0, 0, 0, 0}, att_dma = 0;
+    const long long att_start = __builtin_readcyclecounter();
+#endif
 
     // One key tile.  INTERIOR tiles lie wholly below the diagonal of every wave of the block and inside the sample: no mask is
     // evaluated, no wave skips, the next tile always exists -- straight-line code.  The (at most two + one partial) tiles at the
     // diagonal / end of the sample take the general form.
     auto tile = [&](int t, auto interior_tag) {
         constexpr bool INTERIOR = decltype(interior_tag)::value;
+        ATT_T0();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        ATT_ACC(0);
         ad.shift((t & 1) ? STAGE : -STAGE);
         // interior tiles issue the next tile's staging pieces (8 per wave, 60-100 issue cycles each) behind this tile's score MFMAs (K) and
         // softmax (V) instead of in front of its first fragment read: +2 % (same-box A/B)
-        constexpr bool LATE = INTERIOR;
         char* nx = smem + ((t + 1) & 1) * STAGE;
+        const int kv0 = t * 64;
+        constexpr bool LATE = INTERIOR;
         if (!LATE && (INTERIOR || t + 1 < ntiles)) {
             plK.stage(rsK, (t + 1) * kstep + hoff, nx, wid);
             plV.stage(rsV, (t + 1) * vstep + hoff, nx + TILE, wid);
         }
-        const int kv0 = t * 64;
         if (!INTERIOR && CAUSAL && kv0 > q0 + 31) return;  // every key of this tile is in the future of this wave's rows
 
         f32x4 s[2][4];
@@ -496,6 +511,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
+        ATT_ACC(1);
         // V column fragments of the first two batches are fetched behind the softmax arithmetic
         TFrag vq[3][4];
         constexpr int NB = 2 * DB / 4;
@@ -505,7 +521,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
         };
         issue_v(std::integral_constant<int, 0>{}, vq[0]);
         issue_v(std::integral_constant<int, 1>{}, vq[1]);
+#ifdef RV_ATTN_STAMPS
+        { asm volatile("" ::: "memory"); const long long a_ = __builtin_readcyclecounter();
+          if (LATE) plK.stage(rsK, (t + 1) * kstep + hoff, nx, wid);
+          asm volatile("" ::: "memory"); att_dma += __builtin_readcyclecounter() - a_; }
+#else
         if (LATE) plK.stage(rsK, (t + 1) * kstep + hoff, nx, wid);
+#endif
         // lane holds S^T[key = kv0 + 16kb + 4g + r][q = q0 + 16qs + c]
         const bool edge = !INTERIOR && ((kv0 + 64 > len) || (CAUSAL && kv0 + 63 > q0));     // wave-uniform
         if (edge) {
@@ -603,7 +625,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
             l[qs] += rs;
         }
 #endif
+#ifdef RV_ATTN_STAMPS
+        { asm volatile("" ::: "memory"); const long long a_ = __builtin_readcyclecounter();
+          if (LATE) plV.stage(rsV, (t + 1) * vstep + hoff, nx + TILE, wid);
+          asm volatile("" ::: "memory"); att_dma += __builtin_readcyclecounter() - a_; }
+#else
         if (LATE) plV.stage(rsV, (t + 1) * vstep + hoff, nx + TILE, wid);
+#endif
+        ATT_ACC(2);
         // O^T[d][q] += V^T[d][key] P^T[key][q]
         {
             bf16x8 pf[2][2];
@@ -628,6 +657,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
+#ifdef RV_ATTN_STAMPS
+        ATT_ACC(3);
+        att_dbg[4] += 1;
+#endif
     };
     // interior tiles: below the block's first query row (causal) and wholly inside the sample; never the last tile
     const int n_int = min(CAUSAL ? min(qblk * 2, len >> 6) : (len >> 6), ntiles - 1);
@@ -650,6 +683,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
         }
         if (g == 0 && P.lse) P.lse[(long)(b * P.H + h) * P.S_pad + qidx] = (m[qs] + __builtin_amdgcn_logf(lt)) * LN2;
     }
+#ifdef RV_ATTN_STAMPS
+    if (P.delta && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        att_dbg[5] = __builtin_readcyclecounter() - att_start;
+        att_dbg[4] |= att_dma << 20;          // tiles (low 20 bits) | cycles spent issuing the 8 LDS-DMA pieces of the next tile
+        const long blk = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
+        long long* o_ = (long long*)P.delta + (blk * 4 + wid) * 6;
+        for (int i = 0; i < 6; ++i) o_[i] = att_dbg[i];
+    }
+#endif
 }
 
 
@@ -1346,6 +1389,10 @@ template __global__ void attn_bwd_dkv_nat_kernel<true, 4>(AttnParams);
 template __global__ void attn_bwd_dkv_nat_kernel<false, 4>(AttnParams);
 }  // namespace
 
+#ifdef RV_ATTN_STAMPS
+static float* g_attn_stamp = nullptr;
+extern "C" int rv_debug_set_attn_stamp_buffer(void* p) { g_attn_stamp = (float*)p; return 0; }
+#endif
 extern "C" int rv_attn_fwd_nat(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v, void* out, int64_t ld_o,
                                float* lse, const int32_t* lens, const int32_t* cu_rows, int B, int H, int H_kv, int S, int S_pad, int HD,
                                int causal, float scale, const void* zeros16, void* stream) {
@@ -1356,6 +1403,9 @@ extern "C" int rv_attn_fwd_nat(const void* q, int64_t ld_q, const void* k, int64
     P.q = (const bf16*)q; P.k = (const bf16*)k; P.v = (const bf16*)v; P.out = (bf16*)out; P.lse = lse; P.lens = lens; P.cu = cu_rows;
     P.zeros = (const bf16*)zeros16; P.ld_q = ld_q; P.ld_k = ld_k; P.ld_v = ld_v; P.ld_o = ld_o;
     P.B = B; P.H = H; P.S = S; P.S_pad = S_pad; P.scale = scale; P.Hkv = H_kv; P.nrep = H / H_kv;
+#ifdef RV_ATTN_STAMPS
+    P.delta = g_attn_stamp;
+#endif
     dim3 grid((S + 127) / 128, H, B);
     const int smem = 2 * 2 * 64 * 256;
     if (causal) { set_smem(attn_fwd_nat_kernel<true>, smem); hipLaunchKernelGGL(attn_fwd_nat_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, P); }
