@@ -226,8 +226,9 @@ int rv_dropout_add_bf16(const void* x, void* y, int64_t n, float p, uint64_t see
 /* LoRA down-projection with the adapter's input dropout inside: T[M, R] = alpha / (1 - p) * mask(seed) o X[M, K] * A[R, K]^T
  * = lora_A(lora_dropout(x)) * (alpha / r) of a peft LoraLayer (reference wiring train/train.py:1515-1532, defaults :152-157).
  * The mask is that of rv_dropout_bf16(X as M * K contiguous elements, p, seed) -- backward re-creates dropout(X) with that call --
- * and is applied to the operand fragments in registers: one pass over X instead of three.  X contiguous (ldx == K), K % 64 == 0,
- * R <= 64, R % 4 == 0; p = 0: plain product. */
+ * and is applied to the operand fragments in registers: one pass over X instead of three.  K % 64 == 0, R <= 64, R % 4 == 0; with p > 0 X
+ * must be contiguous (ldx == K: the mask indexes it as M * K elements); p = 0: the plain skinny product at HBM speed, any ldx % 8 == 0
+ * (also used for dT = alpha * dY B, the adapters' backward, with B^T as the row-major operand). */
 /* dx[M, N] (+)= dropout'(alpha * dT[M, K] op(A)): the adapter branch of a LoRA layer's input gradient with the forward's dropout mask
  * (that of rv_dropout_bf16 over M * N elements) applied to the accumulators in the GEMM epilogue.  trans_b: A stored [K, N] (lora_A [r, in]).
  * accumulate != 0: added to dx.  N % 8 == 0. */

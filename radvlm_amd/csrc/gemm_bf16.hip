@@ -1019,9 +1019,9 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
         BAR_LGKM();   // also: every wave's A reads of tile t are complete -> the A halves of this slot may be restaged
         RV_ACC_END(2);
     };
-    if constexpr (MODE == 2 || (MODE == 1 && !BUF)) {
-        // the split-K form and the flat-addressed two-pair form keep the single loop with run-time staging decisions (small outputs /
-        // shapes the buffer-addressed kernel does not take: not the step's bulk)
+    if constexpr ((MODE == 2 || MODE == 1) && !BUF) {
+        // the flat-addressed split-K and two-pair forms keep the single loop with run-time staging decisions (shapes the buffer-addressed
+        // kernel does not take: not the step's bulk)
         for (int t = 0; t < nt; ++t) step(t, std::integral_constant<int, 2>{}, PR);
     } else if constexpr (MODE == 1) {
         // fused second operand pair (LoRA: [x | t] [W | B]^T), buffer-addressed: the steady-state loop stages from the first pair, a
@@ -1247,7 +1247,7 @@ static void launch256m(const GemmParams& P, hipStream_t st) {
 template <bool TA, bool TB>
 static void launch256(GemmParams& P, int mode, hipStream_t st) {
     if (mode == 1) { if (buf_extents(P, TA, TB) && buf_extents2(P, TA, TB)) launch256m<TA, TB, 1, true>(P, st); else launch256m<TA, TB, 1>(P, st); }
-    else if (mode == 2) launch256m<TA, TB, 2>(P, st);
+    else if (mode == 2) { if (buf_extents(P, TA, TB)) launch256m<TA, TB, 2, true>(P, st); else launch256m<TA, TB, 2>(P, st); }
     else if (buf_extents(P, TA, TB)) { if (mode == 3) launch256m<TA, TB, 3, true>(P, st); else launch256m<TA, TB, 0, true>(P, st); }
     else if (mode == 3) launch256m<TA, TB, 3>(P, st);
     else launch256m<TA, TB, 0>(P, st);
@@ -1456,7 +1456,7 @@ extern "C" int rv_lora_down_bf16(const void* X, int64_t ldx, const void* A, int6
                                  float p, uint64_t seed, const void* zeros16, void* stream) {
     if (!X || !A || !T || !zeros16 || M <= 0 || R <= 0 || K <= 0 || p < 0.f || p >= 1.f) return RV_ERR_ARG;
     // the mask indexes X as a contiguous [M, K] tensor (ldx == K), like the dropout kernels backward re-creates it with
-    if (R > LD_BN || (R & 3) || (K % BK) || ldx != K || (lda & 7) || (ldt & 3)) return RV_ERR_ARG;
+    if (R > LD_BN || (R & 3) || (K % BK) || (p > 0.f && ldx != K) || (ldx & 7) || (lda & 7) || (ldt & 3)) return RV_ERR_ARG;
     if ((((uintptr_t)X) | ((uintptr_t)A) | ((uintptr_t)zeros16)) & 15) return RV_ERR_ARG;
     if (((uintptr_t)T) & 7) return RV_ERR_ARG;
     static bool attr = false;

@@ -744,7 +744,8 @@ class LlavaEngine:
             gA, gB = self.G(pre + "lora_A.weight"), self.G(pre + "lora_B.weight")
             dyj = dy[:, c0:c1]
             t = saved[lname]                                        # already scaled by alpha/r
-            dts = ops.gemm(dyj, B, tb=True, alpha=self.lora_scale)    # d(dropout(x) A^T)
+            # d(dropout(x) A^T) = (alpha / r) dy B: an r-wide product over a token-long stream -- the skinny one-pass kernel (B^T is 64 rows)
+            dts = ops.lora_down(dyj, ops.transpose(B), self.lora_scale, 0.0, 0) if B.shape[1] <= 64 else ops.gemm(dyj, B, tb=True, alpha=self.lora_scale)
             ops.gemm(dyj, t, ta=True, tb=True, out=gB, residual=gB if acc else None, workspace=ws)
             first = dx is None
             if first:

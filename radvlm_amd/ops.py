@@ -372,11 +372,11 @@ def lora_down(x, a, alpha, p, seed, out=None):
     r <= 64); other shapes take the two-launch sequence."""
     M, K = x.shape
     r = a.shape[0]
-    if not (x.is_contiguous() and K % 64 == 0 and r <= 64 and r % 4 == 0 and a.stride(1) == 1):
+    if not ((x.is_contiguous() or (p <= 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0)) and K % 64 == 0 and r <= 64 and r % 4 == 0 and a.stride(1) == 1):
         return gemm(dropout(x.contiguous(), p, seed) if p > 0 else x, a, alpha=alpha, out=out)
     if out is None:
         out = torch.empty(M, r, dtype=BF16, device=x.device)
-    lib.call("rv_lora_down_bf16", x, K, a, a.stride(0), out, out.stride(0), M, r, K, float(alpha), float(p), int(seed), lib.zeros16(x.device))
+    lib.call("rv_lora_down_bf16", x, x.stride(0), a, a.stride(0), out, out.stride(0), M, r, K, float(alpha), float(p), int(seed), lib.zeros16(x.device))
     return out
 
 

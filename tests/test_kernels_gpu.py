@@ -765,3 +765,29 @@ def test_gemm_with_dropout_in_the_epilogue(ops, M, N, K, p):
     assert torch.equal(got[~kept & (prod != 0)], y[~kept & (prod != 0)])           # dropped positions are untouched
     fresh = ops.gemm_dropout_add(dt, a, torch.full_like(y, 7.0), p, seed, accumulate=False)
     assert relerr(fresh.float().cpu(), ops.dropout(prod, p, seed).float().cpu()) < TOL
+
+
+def test_skinny_product_on_a_column_slice_and_splitk_buffer_path(ops):
+    """Two launch shapes of the LoRA backward (BASELINE config 5): dT = alpha * dY[:, c0:c1] @ B through rv_lora_down_bf16 without a mask (p = 0
+    lifts the contiguity requirement: dY is a column slice of the fused q|k|v gradient), and the r-wide weight gradients through the
+    buffer-addressed split-K GEMM (rv_gemm_select_kernel 31) against the flat-addressed one (30): bit-identical."""
+    from radvlm_amd import lib
+    M, N, r = 2048, 768, 64
+    dy3 = rnd(330, (M, 3 * N), 1.0).cuda()
+    bmat = rnd(331, (N, r), 0.3).cuda()
+    dyj = dy3[:, N:2 * N]
+    got = ops.lora_down(dyj, ops.transpose(bmat), 0.25, 0.0, 0)
+    want = ops.gemm(dyj, bmat, tb=True, alpha=0.25, out_dtype=torch.float32)
+    assert relerr(got.float().cpu(), want.cpu()) < TOL
+    t = rnd(332, (M, r), 0.5).cuda()
+    ws = torch.empty(8 << 20, dtype=torch.float32, device="cuda")
+    L = lib.load()
+    try:
+        L.rv_gemm_select_kernel(31)
+        g1 = ops.gemm(dyj, t, ta=True, tb=True, workspace=ws, out_dtype=torch.float32)
+        L.rv_gemm_select_kernel(30)
+        g0 = ops.gemm(dyj, t, ta=True, tb=True, workspace=ws, out_dtype=torch.float32)
+    finally:
+        L.rv_gemm_select_kernel(31)
+    assert torch.equal(g0, g1)
+    assert relerr(g1.cpu(), dyj.float().cpu().t() @ t.float().cpu()) < 1e-5
