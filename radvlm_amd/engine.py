@@ -525,8 +525,8 @@ class LlavaEngine:
     def _recompute_layers(self, M):
         """How many decoder layers (the first n) re-run their forward in backward.  False: none -- the activations of all layers stay
         resident (~95 GB for 32 pairs x 704 tokens of the 7B model: what 288 GB of HBM are for); True: all; "auto": as few as the free
-        device memory requires (one 32k-token sample of the reference recipe, finetune_radio_7b.sh:79, needs ~140 GB of activations on
-        top of 108 GB of parameter / optimizer state)."""
+        device memory requires (measured on the 7B geometry: one 32k-token sample of the reference recipe, finetune_radio_7b.sh:79, still
+        fits whole -- 236 GiB peak; a 50k-token sample recomputes 12 of 32 layers)."""
         L = self.l["layers"]
         if self.recompute is True:
             return L
