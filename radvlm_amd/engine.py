@@ -247,7 +247,7 @@ class LlavaEngine:
         k = (key, B, H, s_pad)
         buf = self._stats.get(k)
         if buf is None:
-            if len(self._stats) > 4 * self.l["layers"] + 8:      # shapes change from batch to batch with ragged data: do not hoard
+            if len(self._stats) > 4 * (self.l["layers"] + self.v["layers"]) + 8:      # shapes change from batch to batch with ragged data: do not hoard
                 self._stats.clear()
             buf = self._stats[k] = torch.zeros(B, H, s_pad, dtype=torch.float32, device=self.device)
         return buf
@@ -336,11 +336,13 @@ class LlavaEngine:
             h, st1 = r if keep else (r, None)
             wqkv, bqkv, wo = self._vis_attn_weights(i)
             qkv = ops.gemm_nt(h, wqkv, bias=bqkv)
+            # softmax statistics: one reused buffer for a frozen tower (nobody reads them), one per layer when backward will
+            vlse = self._stat_buffer(("vlse", i if keep else -1), n, H, n_pad)
             if hp == 128:     # natural-layout kernel: no V^T copy
-                a, lse = ops.attn_fwd(qkv[:, :dvp], qkv[:, dvp:2 * dvp], None, n, N, H, hp, n_pad, causal=False, scale=hd ** -0.5, v=qkv[:, 2 * dvp:])
+                a, lse = ops.attn_fwd(qkv[:, :dvp], qkv[:, dvp:2 * dvp], None, n, N, H, hp, n_pad, causal=False, scale=hd ** -0.5, v=qkv[:, 2 * dvp:], lse=vlse)
             else:
                 vT = ops.transpose_heads(qkv[:, 2 * dvp:], n, N, H, hp, n_pad)
-                a, lse = ops.attn_fwd(qkv[:, :dvp], qkv[:, dvp:2 * dvp], vT, n, N, H, hp, n_pad, causal=False, scale=hd ** -0.5)
+                a, lse = ops.attn_fwd(qkv[:, :dvp], qkv[:, dvp:2 * dvp], vT, n, N, H, hp, n_pad, causal=False, scale=hd ** -0.5, lse=vlse)
             x1 = ops.gemm_nt(a, wo, bias=f.view(p + "self_attn.out_proj.bias"), residual=x)
             r = ln(x1, p + "layer_norm2.weight", p + "layer_norm2.bias")
             h2, st2 = r if keep else (r, None)
