@@ -61,8 +61,13 @@ def test_config2_full_size_forward_backward_two_adamw_steps():
     from conftest import ROOT, record_measurement
     t_start = time.time()
     want = os.environ.get("RV_FULLSIZE_LAYERS")
-    layers = int(want) if want else (32 if _avail_gb() >= 180 else 8)
-    geo = copy.deepcopy(GEOMETRIES["llava15_7b"])
+    # RV_FULLSIZE_GEOMETRY=llava_ov_qwen2_7b runs the same comparison on the configuration RadVLM really trains (Qwen2-7B, 28:4
+    # grouped-query heads, q/k/v bias, rope theta 1e6, 152k vocabulary, SigLIP-so400m tower): not part of the suite's default run (another
+    # 2.5 minutes), its record is profiles/r03_full_size_parity_qwen2_siglip.json
+    gname = os.environ.get("RV_FULLSIZE_GEOMETRY", "llava15_7b")
+    full_layers = GEOMETRIES[gname]["lm"]["layers"]
+    layers = int(want) if want else (full_layers if _avail_gb() >= 180 else 8)
+    geo = copy.deepcopy(GEOMETRIES[gname])
     geo["lm"]["layers"] = layers
     V = geo["lm"]["vocab"]
     g = torch.Generator().manual_seed(17)
@@ -72,20 +77,21 @@ def test_config2_full_size_forward_backward_two_adamw_steps():
     ids[:, 35] = -200
     labels[:, 35] = -100
     mask = torch.ones(1, 129, dtype=torch.bool)
-    images = [torch.randn(3, 336, 336, generator=g).to(torch.bfloat16).float()]
+    side = geo["vision"]["image"]
+    images = [torch.randn(3, side, side, generator=g).to(torch.bfloat16).float()]
     lr, wd, clip, b1, b2, eps = 2e-5, 0.05, 1.0, 0.9, 0.999, 1e-8      # the recipe's learning rate (finetune_radio_7b.sh)
 
     eng = LlavaEngine(geo, device="cuda:0", init="fast", seed=11)
     names = eng.lm.names()
     n_params = sum(eng.lm.offsets[n][1] for n in names)
-    if layers == 32:
+    if layers == full_layers:
         assert n_params > 6.7e9, n_params
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     P = {k: v.float().cpu() for k, v in eng.state_dict().items()}         # bf16-exact fp32 copies (27 GB at 32 layers)
     for k in names:
         P[k].requires_grad_(True)
     a = (ids, mask, labels, images)
-    rec = dict(layers=layers, trainable_params=n_params, host_threads=torch.get_num_threads())
+    rec = dict(geometry=gname, layers=layers, trainable_params=n_params, host_threads=torch.get_num_threads())
 
     def dump():
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -152,7 +158,7 @@ def test_config2_full_size_forward_backward_two_adamw_steps():
     t0 = time.time()
     rl1, rlog, aux = oracle_step()
     rec["oracle_fwd_bwd_s"] = time.time() - t0
-    assert aux["inputs_embeds"].shape[1] == 704
+    assert aux["inputs_embeds"].shape[1] == (geo["vision"]["image"] // geo["vision"]["patch"]) ** 2 + 128
     le, lge, _ = E.llava_forward({k: v.detach() for k, v in P.items()}, geo, *a, emulate=True)
     m = pm
     relinf = lambda x, y: float((x[m] - y[m]).abs().max() / y[m].abs().max())
