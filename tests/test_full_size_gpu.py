@@ -198,6 +198,12 @@ def test_config2_full_size_forward_backward_two_adamw_steps():
         assert torch.equal(par, mas.to(torch.bfloat16)), k                      # the bf16 parameters ARE the rounded master copy
         du = (mas - ref).abs() / lr
         mean, bad = float(du.mean()), float((du > 0.5).float().mean())
+        if k.endswith("k_proj.bias"):
+            # Qwen2's key bias: softmax is invariant to a constant key offset, so this gradient is ~0 (only the rotary embedding makes it
+            # position dependent) and AdamW's normalised direction m / sqrt(v) of a ~0 gradient is rounding noise on both sides (measured
+            # mean 0.45 lr); the gradient itself is gated above like every other tensor
+            rec.setdefault("update_key_bias_mean_over_lr", []).append(round(mean, 3))
+            continue
         if mean > worst_mean[0]:
             worst_mean = (mean, k)
         if bad > worst_bad[0]:
