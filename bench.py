@@ -190,6 +190,21 @@ class GemmTimer:
         return flops, ms, len(self.records), sum(r[3] for r in self.records)
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on STDOUT when its first communicator is created; the contract is ONE JSON line on stdout, so file
+    descriptor 1 points at stderr while the process group comes up (fd level: the banner is written by the C library)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,6 +259,9 @@ def main():
     torch.cuda.set_device(local)
     pg = None
     force_pg = args.force_process_group and world == 1
+    quiet = _StdoutToStderr()
+    if world > 1 or force_pg:
+        quiet.__enter__()
     if force_pg:
         import socket
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -266,6 +284,8 @@ def main():
         torch.distributed.all_reduce(seen)
         ranks_seen, backend = int(seen.sum()), torch.distributed.get_backend()
         assert ranks_seen == world, f"{ranks_seen} of {world} ranks answered"
+        torch.cuda.synchronize()
+        quiet.__exit__()          # the communicator exists now (first collective done): stdout is ours again
     # GEMM round planning budget: the device's CU count minus what --reserved-cus leaves to the RCCL kernels that run beside backward
     reserved = args.reserved_cus if args.reserved_cus is not None else int(os.environ.get("RV_GEMM_RESERVED_CUS", "0"))
     cu_budget = lib.load().rv_gemm_set_cu_budget(0, reserved)

@@ -20,6 +20,8 @@ def _run(extra, env=None):
                         "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert p.returncode == 0 and len(lines) == 1, p.stdout[-1500:] + p.stderr[-1500:]
+    # ONE line on stdout, nothing else (RCCL's version banner, printed when the first communicator comes up, must not land there)
+    assert [l for l in p.stdout.splitlines() if l.strip()] == lines, p.stdout[:1500]
     return json.loads(lines[0])
 
 
