@@ -142,6 +142,10 @@ class LlavaEngine:
             # persistent block that cannot start would delay its whole share of the tiles (rv_gemm_select_kernel, include/radvlm_hip.h)
             from . import lib
             lib.load().rv_gemm_select_kernel(40)
+        elif self.device.type == "cuda":
+            # the switch is process-wide: an engine without gradient collectives created after one with them gets the persistent blocks back
+            from . import lib
+            lib.load().rv_gemm_select_kernel(41)
         self.ctx = None
         self.grad_accum_started = False
         self.loss_scale = 1.0
