@@ -333,12 +333,15 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0          # this rank's own K steps, before it waits for the others (straggler spread, N > 1)
     fence()
     dt = time.perf_counter() - t0
+    dt_min = dt_max = dt_own
     if world > 1:
-        t = torch.tensor([dt], device=f"cuda:{local}")
+        t = torch.tensor([dt, dt_own, -dt_own], device=f"cuda:{local}")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t)
+        dt, dt_max, dt_min = float(t[0]), float(t[1]), -float(t[2])
     final_loss = float(loss)
     ms_per_step = dt / args.steps * 1e3
     pairs = args.batch * world * args.steps
@@ -417,7 +420,11 @@ def main():
             "roofline": roofline,
             "distributed": {"world": world, "ranks_seen": ranks_seen, "backend": backend if not rehearsal else f"{backend} (rehearsal: all ranks on one GPU)",
                             "grad_sync": None if eng.sync is None else "bucketed sum-all-reduce of the flat bf16 gradient buffer, per-layer buckets on a side stream",
-                            "exposed_comm_ms_per_step": comm_wait_ms, "gemm_cu_budget": cu_budget, "reserved_cus": reserved},
+                            "exposed_comm_ms_per_step": comm_wait_ms, "gemm_cu_budget": cu_budget, "reserved_cus": reserved,
+                            # each rank's own time for the K steps before the closing barrier: max - min = straggler spread over ranks
+                            "ms_per_step_min": dt_min / args.steps * 1e3, "ms_per_step_max": dt_max / args.steps * 1e3,
+                            "bucket_count": None if eng.sync is None else len(eng.sync.last_buckets),
+                            "bucket_mbytes": None if eng.sync is None else [round((e - s) * 2 / 2 ** 20, 1) for s, e in eng.sync.last_buckets][:4] + ["..."] * (len(eng.sync.last_buckets) > 4)},
             "build": {"kernel_source_sha256": src_hash},
         }
         if not args.no_cpu_baseline and world == 1:

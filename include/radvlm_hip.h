@@ -177,9 +177,10 @@ int rv_attn_fwd_gqa(const void* q, int64_t ld_q, const void* k, int64_t ld_k, co
 int rv_attn_fwd_nat(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v, void* out, int64_t ld_o,
                     float* lse, const int32_t* lens, const int32_t* cu_rows, int B, int H, int H_kv, int S, int S_pad, int hd, int causal,
                     float scale, const void* zeros16, void* stream);
-/* Kernel family behind the head_dim 128 natural-layout entry points (rv_attn_fwd_nat / rv_attn_bwd_nat), process-wide.  Measurement
- * hook (A/B tools and tests only): 0 = one wave per SIMD, 64 query rows / keys per wave (attention_w64.hip; default),
- * 1 = round 3's two-waves-per-SIMD kernels (attention.hip).  Same results up to the rounding of the running maximum's granularity. */
+/* Kernel family behind the head_dim 128 natural-layout forward (rv_attn_fwd_nat), process-wide.  Measurement hook (A/B tools and tests
+ * only): 0 = default, 1 = two waves per SIMD, 32 query rows per wave (attention.hip; what the default selects), 2 = one wave per SIMD,
+ * 64 query rows per wave, hand-placed softmax (attention_w64.hip; measured slower, kept for the A/B record).  Same results up to the
+ * rounding of the running maximum's granularity (64- vs 32-key steps). */
 int rv_attn_select_kernel(int which);
 int rv_attn_bwd_gqa(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v, const void* o,
                     int64_t ld_o, const void* dout, int64_t ld_do, const void* qT, const void* kT, const void* doT,

@@ -168,20 +168,8 @@ def vision_tower(P, geo, pixels, rnd, fused_act=True):
         cls = P[vp + "embeddings.class_embedding"].expand(n, 1, -1)
         x = rnd(torch.cat([cls, x], dim=1) + P[vp + "embeddings.position_embedding.weight"][None])
         x = layernorm(x, P[vp + "pre_layrnorm.weight"], P[vp + "pre_layrnorm.bias"], eps, rnd)
-    N, d, H = x.shape[1], v["d"], v["heads"]
-    hd = d // H
-    act = (lambda t: F.gelu(t, approximate="tanh")) if siglip else O.quick_gelu
     for i in range(v["layers"] - 1):
-        p = vp + f"encoder.layers.{i}."
-        h = layernorm(x, P[p + "layer_norm1.weight"], P[p + "layer_norm1.bias"], eps, rnd)
-        q, k, vv = (rnd(F.linear(h, P[p + f"self_attn.{t}_proj.weight"], P[p + f"self_attn.{t}_proj.bias"])).view(n, N, H, hd).transpose(1, 2)
-                    for t in "qkv")
-        a = attention(q, k, vv, None, False, hd ** -0.5, rnd, int_max=nat_kernel_head_dim(hd)).transpose(1, 2).reshape(n, N, d)
-        x = rnd(F.linear(a, P[p + "self_attn.out_proj.weight"], P[p + "self_attn.out_proj.bias"]) + x)
-        h = layernorm(x, P[p + "layer_norm2.weight"], P[p + "layer_norm2.bias"], eps, rnd)
-        z = F.linear(h, P[p + "mlp.fc1.weight"], P[p + "mlp.fc1.bias"])
-        g = rnd(act(z)) if fused_act else rnd(act(rnd(z)))
-        x = rnd(F.linear(g, P[p + "mlp.fc2.weight"], P[p + "mlp.fc2.bias"]) + x)
+        x, _ = vision_layer(x, P, vp + f"encoder.layers.{i}.", v, rnd, fused_act=fused_act)
     return x if siglip else x[:, 1:]
 
 
@@ -256,18 +244,18 @@ def unrope(x, cos, sin, rnd):
     return rnd(torch.cat((a * cos + b * sin, b * cos - a * sin), dim=-1))
 
 
-def attention_lse(q, k, lens, scale):
+def attention_lse(q, k, lens, scale, causal=True):
     """Natural-log softmax normaliser of the causal + key-padding masked scores, [b,h,S] (what the forward kernel leaves for backward)."""
     b, h, S, hd = q.shape
     nrep = h // k.shape[1]
     s = torch.matmul(q, k.repeat_interleave(nrep, dim=1).transpose(2, 3)) * scale
-    ok = torch.tril(torch.ones(S, S, dtype=torch.bool))[None, None]
+    ok = (torch.tril(torch.ones(S, S, dtype=torch.bool)) if causal else torch.ones(S, S, dtype=torch.bool))[None, None]
     if lens is not None:
         ok = ok & (torch.arange(S)[None, None, None, :] < torch.as_tensor(lens)[:, None, None, None])
     return torch.logsumexp(s.masked_fill(~ok, -math.inf), dim=-1)
 
 
-def attention_bwd(q, k, v, o, do, lse, lens, scale, rnd, cos=None, sin=None, group_partials_bf16=False):
+def attention_bwd(q, k, v, o, do, lse, lens, scale, rnd, cos=None, sin=None, group_partials_bf16=False, causal=True):
     """q, o, do [b,h,S,hd]; k, v [b,kvh,S,hd] (q, k rotated); lse [b,h,S].  Returns (dq, dk, dv) as the kernels store them: gradients of
     the UN-rotated q / k when cos / sin are given.  group_partials_bf16: the grouped-query launch shape that writes one bf16 dK / dV
     partial per QUERY head and sums the group afterwards (rv_attn_bwd_nat with a workspace and a small grid) -- one more store point."""
@@ -275,7 +263,7 @@ def attention_bwd(q, k, v, o, do, lse, lens, scale, rnd, cos=None, sin=None, gro
     kvh = k.shape[1]
     nrep = h // kvh
     kk, vv = k.repeat_interleave(nrep, dim=1), v.repeat_interleave(nrep, dim=1)
-    ok = torch.tril(torch.ones(S, S, dtype=torch.bool))[None, None]
+    ok = (torch.tril(torch.ones(S, S, dtype=torch.bool)) if causal else torch.ones(S, S, dtype=torch.bool))[None, None]
     if lens is not None:
         ln = torch.as_tensor(lens)[:, None, None, None]
         ok = ok & (torch.arange(S)[None, None, None, :] < ln) & (torch.arange(S)[None, None, :, None] < ln)
@@ -335,3 +323,207 @@ def decoder_layer_backward(T, P, pre, l, lens, dx_out, rnd, rope_adjoint=True, g
     out["dh1"] = dh1 = rnd(F.linear(dqkv, wqkv.t()))
     out["dx_in"], out["g_ln1"] = rmsnorm_bwd(dh1, x, W("input_layernorm.weight"), eps, dx_mid, rnd)
     return out
+
+
+# ----------------------------------------------------------------------------- vision tower layer, projector, head: traces + backward
+# Same construction as the decoder layer above, for the rest of the trainable path (the RadVLM recipe tunes the tower too,
+# finetune_radio_7b.sh:52): forward functions that record every stored tensor, and their derivatives written out op by op with a bf16
+# rounding exactly where the HIP backward stores bf16.  Reference text: HF modeling_clip.py:202-384 (CLIPEncoderLayer: pre-LN attention +
+# quick_gelu MLP), siglip_encoder.py:148-306 (same block with gelu_tanh, head_dim 72), multimodal_projector/builder.py:41-48 (mlp2x_gelu),
+# modeling_llama.py:1323-1337 (lm_head + shifted cross entropy).  Pinning: with rnd = identity every backward below equals torch autograd
+# of its own forward to 1e-5 (tests/test_oracle_golden.py::test_bf16_emulation_tower_head_backward_reduces_to_autograd), and the forwards
+# are the code `vision_tower` / `mm_projector` / `llama_forward` run, which are pinned to the reference-pinned oracle.
+VP = "model.vision_tower.vision_tower.vision_model."
+
+
+def _act_pair(siglip):
+    if siglip:
+        k = 0.7978845608028654
+
+        def fwd(z):
+            return F.gelu(z, approximate="tanh")
+
+        def grad(z):
+            t = torch.tanh(k * (z + 0.044715 * z ** 3))
+            return 0.5 * (1.0 + t) + 0.5 * z * (1.0 - t * t) * k * (1.0 + 0.134145 * z * z)
+        return fwd, grad
+
+    def grad(z):
+        sg = torch.sigmoid(1.702 * z)
+        return sg * (1.0 + 1.702 * z * (1.0 - sg))
+    return O.quick_gelu, grad
+
+
+def layernorm_bwd(dy, x, w, eps, dx_in, rnd):
+    """Backward of `layernorm`: (rnd(dx_in + dx), fp32 dw, fp32 db); dw / db are sums over all rows."""
+    mean = x.mean(-1, keepdim=True)
+    rstd = torch.rsqrt((x - mean).pow(2).mean(-1, keepdim=True) + eps)
+    xh = (x - mean) * rstd
+    g = dy * w
+    dx = rstd * (g - g.mean(-1, keepdim=True) - xh * (g * xh).mean(-1, keepdim=True))
+    flat = lambda t: t.reshape(-1, t.shape[-1])
+    return rnd((dx_in if dx_in is not None else 0.0) + dx), flat(dy * xh).sum(0), flat(dy).sum(0)
+
+
+def vision_layer(x, P, p, v, rnd, fused_act=False):
+    """One pre-LN encoder layer of the CLIP / SigLIP tower as the engine runs it (LlavaEngine.vision_forward): returns (x_out, T) with T
+    the stored tensors {x, h, qkv, a, x1, h2, z, g}.  fused_act: fc1's activation in the GEMM epilogue (frozen tower: z is not stored)."""
+    siglip = v.get("kind") == "siglip"
+    eps = 1e-6 if siglip else 1e-5
+    n, N, d = x.shape
+    H = v["heads"]
+    hd = d // H
+    act, _ = _act_pair(siglip)
+    T = {"x": x}
+    T["h"] = h = layernorm(x, P[p + "layer_norm1.weight"], P[p + "layer_norm1.bias"], eps, rnd)
+    T["qkv"] = qkv = torch.cat([rnd(F.linear(h, P[p + f"self_attn.{t}_proj.weight"], P[p + f"self_attn.{t}_proj.bias"])) for t in "qkv"], -1)
+    heads = lambda t: t.view(n, N, H, hd).transpose(1, 2)
+    q, k, vv = heads(qkv[..., :d]), heads(qkv[..., d:2 * d]), heads(qkv[..., 2 * d:])
+    T["a"] = a = attention(q, k, vv, None, False, hd ** -0.5, rnd, int_max=nat_kernel_head_dim(hd)).transpose(1, 2).reshape(n, N, d)
+    T["x1"] = x1 = rnd(F.linear(a, P[p + "self_attn.out_proj.weight"], P[p + "self_attn.out_proj.bias"]) + x)
+    T["h2"] = h2 = layernorm(x1, P[p + "layer_norm2.weight"], P[p + "layer_norm2.bias"], eps, rnd)
+    z = F.linear(h2, P[p + "mlp.fc1.weight"], P[p + "mlp.fc1.bias"])
+    if fused_act:
+        T["g"] = g = rnd(act(z))
+    else:
+        T["z"] = z = rnd(z)
+        T["g"] = g = rnd(act(z))
+    return rnd(F.linear(g, P[p + "mlp.fc2.weight"], P[p + "mlp.fc2.bias"]) + x1), T
+
+
+def vision_layer_backward(T, P, p, v, dx_out, rnd):
+    """Backward of `vision_layer` (tower tunable: z stored) for the upstream gradient dx_out [n,N,d], in the order of
+    LlavaEngine.vision_backward.  Every entry is a tensor the HIP backward stores (weight / bias / norm gradients as fp32 sums)."""
+    from collections import OrderedDict
+    siglip = v.get("kind") == "siglip"
+    eps = 1e-6 if siglip else 1e-5
+    n, N, d = dx_out.shape
+    H = v["heads"]
+    hd = d // H
+    _, dact = _act_pair(siglip)
+    flat = lambda t: t.reshape(-1, t.shape[-1])
+    wsum = lambda dy, xin: flat(dy).t().double().matmul(flat(xin).double()).float()
+    W = lambda nm: P[p + nm]
+    out = OrderedDict()
+    out["g_fc2_b"] = flat(dx_out).sum(0)
+    out["gW_fc2"] = wsum(dx_out, T["g"])
+    out["dg"] = dg = rnd(F.linear(dx_out, W("mlp.fc2.weight").t()))
+    out["dz"] = dz = rnd(dg * dact(T["z"]))
+    out["g_fc1_b"] = flat(dz).sum(0)
+    out["gW_fc1"] = wsum(dz, T["h2"])
+    out["dh2"] = dh2 = rnd(F.linear(dz, W("mlp.fc1.weight").t()))
+    out["dx1"], out["g_ln2_w"], out["g_ln2_b"] = layernorm_bwd(dh2, T["x1"], W("layer_norm2.weight"), eps, dx_out, rnd)
+    dx1 = out["dx1"]
+    out["g_out_b"] = flat(dx1).sum(0)
+    out["gW_out"] = wsum(dx1, T["a"])
+    out["da"] = da = rnd(F.linear(dx1, W("self_attn.out_proj.weight").t()))
+    heads = lambda t: t.view(n, N, H, hd).transpose(1, 2)
+    qkv = T["qkv"]
+    q, k, vv = heads(qkv[..., :d]), heads(qkv[..., d:2 * d]), heads(qkv[..., 2 * d:])
+    scale = hd ** -0.5
+    out["lse"] = lse = attention_lse(q, k, None, scale, causal=False)
+    dq, dk, dv = attention_bwd(q, k, vv, heads(T["a"]), heads(da), lse, None, scale, rnd, causal=False)
+    back = lambda t: t.transpose(1, 2).reshape(n, N, d)
+    out["dqkv"] = dqkv = torch.cat((back(dq), back(dk), back(dv)), -1)
+    out["g_bqkv"] = flat(dqkv).sum(0)
+    out["gW_qkv"] = wsum(dqkv, T["h"])
+    wqkv = torch.cat([W(f"self_attn.{t}_proj.weight") for t in "qkv"], 0)
+    out["dh"] = dh = rnd(F.linear(dqkv, wqkv.t()))
+    out["dx_in"], out["g_ln1_w"], out["g_ln1_b"] = layernorm_bwd(dh, T["x"], W("layer_norm1.weight"), eps, dx1, rnd)
+    return out
+
+
+def gelu_grad(z):
+    """d/dz of the exact (erf) GELU of mlp2x_gelu."""
+    return 0.5 * (1.0 + torch.erf(z * 0.7071067811865476)) + z * 0.3989422804014327 * torch.exp(-0.5 * z * z)
+
+
+def mm_projector_backward(T, P, dproj, rnd):
+    """Backward of `mm_projector` through its trace {f0, z1, a1} for the gradient of its output rows dproj [rows, d_lm]."""
+    from collections import OrderedDict
+    w0, w2 = P["model.mm_projector.0.weight"], P["model.mm_projector.2.weight"]
+    flat = lambda t: t.reshape(-1, t.shape[-1])
+    wsum = lambda dy, xin: flat(dy).t().double().matmul(flat(xin).double()).float()
+    out = OrderedDict()
+    out["g_b2"] = flat(dproj).sum(0)
+    out["gW2"] = wsum(dproj, T["a1"])
+    out["da1"] = da1 = rnd(F.linear(dproj, w2.t()))
+    out["dz1"] = dz1 = rnd(da1 * gelu_grad(T["z1"]))
+    out["g_b0"] = flat(dz1).sum(0)
+    out["gW0"] = wsum(dz1, T["f0"])
+    out["df0"] = rnd(F.linear(dz1, w0.t()))
+    return out
+
+
+def lm_head_cross_entropy(hN, w_head, targets, gscale, rnd):
+    """lm_head + shifted cross entropy as the engine evaluates them (modeling_llama.py:1323-1337): logits stored bf16, per-row loss and
+    softmax in fp32 from the STORED logits, dlogits = (softmax - onehot) * gscale / count stored bf16 over the logits, then the head's
+    input gradient (one rounding) and weight gradient (fp32 sum).  targets: already shifted, -100 = ignored row.  Returns a dict."""
+    logits = rnd(F.linear(hN, w_head))
+    rows = targets != -100
+    count = int(rows.sum())
+    lse = torch.logsumexp(logits, -1)
+    tgt = logits.gather(-1, targets.clamp_min(0)[..., None])[..., 0]
+    loss_rows = torch.where(rows, lse - tgt, torch.zeros_like(lse))
+    p = torch.exp(logits - lse[..., None])
+    onehot = F.one_hot(targets.clamp_min(0), logits.shape[-1]).to(p.dtype)
+    dlogits = rnd(torch.where(rows[..., None], (p - onehot) * (gscale / max(count, 1)), torch.zeros_like(p)))
+    flat = lambda t: t.reshape(-1, t.shape[-1])
+    return dict(logits=logits, loss_rows=loss_rows, loss=loss_rows.sum() / max(count, 1), dlogits=dlogits,
+                dhN=rnd(F.linear(dlogits, w_head.t())), gW_head=flat(dlogits).t().double().matmul(flat(hN).double()).float())
+
+
+# ----------------------------------------------------------------------------- LoRA: the counter-based dropout mask and the adapted linear
+# peft LoraLayer (train/train.py:1515-1532): y = x W^T + (alpha / r) * dropout_p(x) A^T B^T, an independent mask per adapted module, on
+# the adapter's input only.  The HIP path regenerates its masks from (seed, element index) -- common.h rv_hash64 / rv_keep8, restated here
+# bit for bit -- so an emulation can apply THE SAME mask (peft is absent and the reference holds no LoRA fixture: parity unpinned upstream).
+_M64 = (1 << 64) - 1
+
+
+def _hash64(seed, b):
+    import numpy as np
+    with np.errstate(over="ignore"):
+        z = (b + np.uint64((seed * 0x9E3779B97F4A7C15) & _M64)) + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def dropout_keep_mask(shape, p, seed):
+    """Boolean keep mask of rv_dropout_bf16(x viewed as contiguous elements, p, seed): one splitmix64 value per four consecutive
+    elements, element i kept when bits [16 (i & 3), +16) of hash(seed, i >> 2) >= round(p * 2^16)."""
+    import numpy as np
+    n = 1
+    for s in shape:
+        n *= int(s)
+    thr = int(p * 65536.0 + 0.5)
+    i = np.arange(n, dtype=np.uint64)
+    h = _hash64(int(seed), i >> np.uint64(2))
+    field = (h >> (np.uint64(16) * (i & np.uint64(3)))) & np.uint64(0xFFFF)
+    return torch.from_numpy((field >= np.uint64(thr)).reshape(tuple(int(s) for s in shape)))
+
+
+def lora_linear(x, W, A, B, scale, p, seed, rnd, bias=None, residual=None):
+    """(y, t): t = rnd(scale / (1 - p) * (keep * x) A^T) -- the 1 / (1 - p) rides the scale, the masked x is not rounded
+    (rv_lora_down_bf16) -- and y = rnd(x W^T + t B^T + bias + residual) in ONE store (the adapter rides the base GEMM)."""
+    keep = dropout_keep_mask(x.shape, p, seed).to(x.dtype) if p > 0 else torch.ones_like(x)
+    t = rnd(F.linear(x * keep, A) * (scale / (1.0 - p) if p > 0 else scale))
+    y = F.linear(x, W, bias) + F.linear(t, B)
+    return rnd(y + (residual if residual is not None else 0.0)), t
+
+
+def lora_linear_backward(dy, x, W, A, B, t, scale, p, seed, rnd):
+    """Backward of `lora_linear` as LlavaEngine._lora_linear_bwd stores it: dts = rnd(scale * dy B) (r-wide), gB = dy^T t and
+    gA = dts^T dropout(x) (fp32 sums; dropout(x) = rnd(keep * x / (1 - p)) is a stored tensor there), the base input gradient
+    rnd(dy W) and the adapter branch added through the masked epilogue: dx = rnd(dx_base + keep * (dts A) / (1 - p))."""
+    flat = lambda u: u.reshape(-1, u.shape[-1])
+    keep = dropout_keep_mask(x.shape, p, seed).to(x.dtype) if p > 0 else torch.ones_like(x)
+    dts = rnd(F.linear(dy, B.t()) * scale)
+    gB = flat(dy).t().double().matmul(flat(t).double()).float()
+    xd = rnd(x * keep / (1.0 - p)) if p > 0 else x
+    gA = flat(dts).t().double().matmul(flat(xd).double()).float()
+    if p > 0:
+        dx = rnd(rnd(F.linear(dy, W.t())) + keep * F.linear(dts, A.t()) / (1.0 - p))
+    else:
+        dx = rnd(F.linear(dy, W.t()) + F.linear(dts, A.t()))      # second operand pair of the same GEMM: one store
+    return dict(dts=dts, gA=gA, gB=gB, dx=dx)

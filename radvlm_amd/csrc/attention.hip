@@ -260,6 +260,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
     const int kstep = (int)(64 * P.ld_k * 2), vstep = (int)(64 * P.ld_v * 2), hoff = hk * HD * 2;
 
     float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+    float thr[2] = {-INFINITY, -INFINITY};        // (m + RESCALE_LAG) / sl2: the first tile always takes the rescale branch
+    const float inv_sl2 = 1.f / sl2;
     f32x4 o[2][DB];
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs)
@@ -399,6 +401,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
         }
 #else
         constexpr float RESCALE_LAG = 8.f;
+#ifdef RV_ATTN_ROW_MAX_EVERY_TILE     // A/B switch (measurement only): round 3's cross-lane row maximum + candidate on every tile
         float cand[2];
         bool need = false;
 #pragma unroll
@@ -422,6 +425,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
                 for (int db = 0; db < DB; ++db) o[qs][db] *= alpha;
             }
         }
+#else
+        // A row needs a new maximum only when one of its scores outgrows the stored one by more than 2^RESCALE_LAG -- a test every lane
+        // makes on its OWN 16 scores against thr = (m + RESCALE_LAG) / sl2 (raw-score units).  The cross-lane row maximum (two LDS
+        // permutes whose wait also drained the V fragment reads in flight), the candidate and the rescale only run in the rare branch.
+        const bool need = (mxa[0] > thr[0]) | (mxa[1] > thr[1]);
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {         // wave-uniform
+#pragma unroll
+            for (int qs = 0; qs < 2; ++qs) {
+                float mx = mxa[qs];
+                float sh = __shfl_xor(mx, 16, 64);
+                mx = max3_asm(mx, sh, sh);
+                sh = __shfl_xor(mx, 32, 64);
+                mx = max3_asm(mx, sh, sh);
+                const float cand = ceilf(mx * sl2);               // scale > 0: the maximum commutes with the scaling
+                const float mnew = max3_asm(m[qs], cand, cand);
+                const float alpha = fexp2(m[qs] - mnew);          // 2^(integer) or 0 (m = -inf before the first tile)
+                l[qs] *= alpha;
+                m[qs] = mnew;
+                thr[qs] = (mnew + RESCALE_LAG) * inv_sl2;
+#pragma unroll
+                for (int db = 0; db < DB; ++db) o[qs][db] *= alpha;
+            }
+        }
+#endif
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) {
             float rs = 0.f;
@@ -1202,16 +1229,17 @@ template __global__ void attn_bwd_dkv_nat_kernel<false, 4>(AttnParams);
 
 // one-wave-per-SIMD kernels (attention_w64.hip)
 int rv_attn_fwd_w64_launch(const AttnParams& P, int causal, hipStream_t st);
-// Kernel-family selection of the head_dim 128 natural-layout entry points, process-wide (measurement hook: same-process A/B and the
-// bit-for-bit comparison tests): 0 = one wave per SIMD (attention_w64.hip, default), 1 = round 3's two-waves-per-SIMD kernels.
+// Kernel-family selection of the head_dim 128 natural-layout entry points, process-wide (measurement hook: same-process A/B and tests):
+// 0 = default (the two-waves-per-SIMD kernels of this file: faster on every shape measured, profiles/r04_ab_attn_w64_*), 1 = the same,
+// explicitly, 2 = the one-wave-per-SIMD forward of attention_w64.hip.
 static int g_attn_family = 0;
 extern "C" int rv_attn_select_kernel(int which) {
-    if (which < 0 || which > 1) return RV_ERR_ARG;
+    if (which < 0 || which > 2) return RV_ERR_ARG;
     g_attn_family = which;
     return RV_OK;
 }
 
-#ifdef RV_ATTN_STAMPS
+#if defined(RV_ATTN_STAMPS) || defined(RV_W64_STAMPS)
 static float* g_attn_stamp = nullptr;
 extern "C" int rv_debug_set_attn_stamp_buffer(void* p) { g_attn_stamp = (float*)p; return 0; }
 #endif
@@ -1225,10 +1253,10 @@ extern "C" int rv_attn_fwd_nat(const void* q, int64_t ld_q, const void* k, int64
     P.q = (const bf16*)q; P.k = (const bf16*)k; P.v = (const bf16*)v; P.out = (bf16*)out; P.lse = lse; P.lens = lens; P.cu = cu_rows;
     P.zeros = (const bf16*)zeros16; P.ld_q = ld_q; P.ld_k = ld_k; P.ld_v = ld_v; P.ld_o = ld_o;
     P.B = B; P.H = H; P.S = S; P.S_pad = S_pad; P.scale = scale; P.Hkv = H_kv; P.nrep = H / H_kv;
-#ifdef RV_ATTN_STAMPS
+#if defined(RV_ATTN_STAMPS) || defined(RV_W64_STAMPS)
     P.delta = g_attn_stamp;
 #endif
-    if (g_attn_family == 0) return rv_attn_fwd_w64_launch(P, causal, (hipStream_t)stream);
+    if (g_attn_family == 2) return rv_attn_fwd_w64_launch(P, causal, (hipStream_t)stream);
     dim3 grid((S + 127) / 128, H, B);
     const int smem = 2 * 2 * 64 * 256;
     if (causal) { set_smem(attn_fwd_nat_kernel<true>, smem); hipLaunchKernelGGL(attn_fwd_nat_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, P); }

@@ -63,6 +63,9 @@ DEVINL void a_swap32(float& a, float& b) { asm volatile("v_permlane32_swap_b32 %
 
 // One 1-KiB LDS-DMA piece of a natural tile (see NatPlan): piece i of wave wid = rows (4 i + wid) 4 .. + 3 of the tile.
 DEVINL void w_piece(__amdgpu_buffer_rsrc_t rsrc, int v0, int soff, char* lds) {
+#if defined(RV_W64_EXP) && RV_W64_EXP == 4
+    return;
+#endif
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, v0, soff, 0, 0);
 }
 
@@ -92,6 +95,16 @@ DEVINL void mfma_settle() { asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); }
     "a96","a97","a98","a99","a100","a101","a102","a103","a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127", \
     "a128","a129","a130","a131","a132","a133","a134","a135","a136","a137","a138","a139","a140","a141","a142","a143","a144","a145","a146","a147","a148","a149","a150","a151","a152","a153","a154","a155","a156","a157","a158","a159", \
     "a160","a161","a162","a163","a164","a165","a166","a167","a168","a169","a170","a171","a172","a173","a174","a175","a176","a177","a178","a179","a180","a181","a182","a183","a184","a185","a186","a187","a188","a189","a190","a191"
+
+#ifdef RV_W64_STAMPS
+// Diagnostic build only (tools/attn_w64_stamps.py; build with -DRV_W64_STAMPS): per-wave cycle sums of the tile loop's sections -> P.delta
+// (unused by the forward), as long long [blocks][4 waves][8].  The stamp's own lgkmcnt(0) drains the fragment reads in flight: read SHARES.
+#define W_T0() long long w_t = __builtin_readcyclecounter()
+#define W_ACC(k) do { const long long n_ = __builtin_readcyclecounter(); w_dbg[k] += n_ - w_t; w_t = n_; } while (0)
+#else
+#define W_T0() do { } while (0)
+#define W_ACC(k) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------ forward
 // accumulator file: O^T[qs][db] = a[(qs * 8 + db) * 4 ..], Q fragment [qs][ks] = a[128 + (qs * 4 + ks) * 4 ..]
@@ -137,7 +150,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnParams P) {
     const int ntiles = (kv_end + 63) >> 6;                                       // block-uniform: every wave stages and meets every barrier
     const int t_last = q0 < S ? (CAUSAL ? min(ntiles - 1, q0 >> 6) : ntiles - 1) : -1;   // this wave's last tile with an unmasked key
     const int hk = h / P.nrep;
+#if defined(RV_W64_EXP) && RV_W64_EXP == 3
+    const __amdgpu_buffer_rsrc_t rsK = rows_rsrc(P.k + rb * P.ld_k, 0, P.ld_k), rsV = rows_rsrc(P.v + rb * P.ld_v, 0, P.ld_v);
+#else
     const __amdgpu_buffer_rsrc_t rsK = rows_rsrc(P.k + rb * P.ld_k, S, P.ld_k), rsV = rows_rsrc(P.v + rb * P.ld_v, S, P.ld_v);
+#endif
     int kv0_, vv0_, kpstep, vpstep;
     {
         const int cc = wid * 64 + lane, r = cc >> 4, pch = cc & 15;
@@ -147,19 +164,19 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnParams P) {
         vpstep = (int)(16 * P.ld_v * 2);
     }
     const int ktstep = (int)(64 * P.ld_k * 2), vtstep = (int)(64 * P.ld_v * 2), hoff = hk * HD * 2;
-    auto stage_k = [&](int tt) __attribute__((always_inline)) {
+    // pieces [i0, i0 + n) of tile tt's K / V image (4 per wave and image)
+    auto stage_k = [&](int tt, int i0 = 0, int n = 4) __attribute__((always_inline)) {
         char* dst = smem + (tt & 3) * W_TILE + wid * 1024;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w_piece(rsK, kv0_, tt * ktstep + hoff + i * kpstep, dst + i * 4096);
+        for (int i = i0; i < i0 + n; ++i) w_piece(rsK, kv0_, tt * ktstep + hoff + i * kpstep, dst + i * 4096);
     };
-    auto stage_v = [&](int tt) __attribute__((always_inline)) {
+    auto stage_v = [&](int tt, int i0 = 0, int n = 4) __attribute__((always_inline)) {
         char* dst = smem + W_VBASE + (tt & 3) * W_TILE + wid * 1024;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w_piece(rsV, vv0_, tt * vtstep + hoff + i * vpstep, dst + i * 4096);
+        for (int i = i0; i < i0 + n; ++i) w_piece(rsV, vv0_, tt * vtstep + hoff + i * vpstep, dst + i * 4096);
     };
 
     float m[4], l[4];
     sfor<4>([&](auto qt) __attribute__((always_inline)) { m[decltype(qt)::value] = -INFINITY; l[decltype(qt)::value] = 0.f; });
+    const float inv_sl2 = 1.f / sl2;
     sfor<128>([&](auto it) __attribute__((always_inline)) { acc_zero<decltype(it)::value>(); });
     if (ntiles > 0) { stage_k(0); stage_v(0); }
     if (ntiles > 1) { stage_k(1); stage_v(1); }
@@ -182,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnParams P) {
 
     f32x4 s0[4][2], s1[4][2];       // scores of the two 32-key halves: s[qs][kbl][r] = S^T[key = 32 kp + 16 kbl + 4 g + r][q = 16 qs + c]
     u32x4 pf[4];                    // bf16 probabilities of one half, packed in contraction order (the P V product's B operand)
-    float mx[4], pv[32];            // pv: t = s * sl2 - m, then p = exp2(t), of the half that is being exponentiated
+    float mx[4] = {0.f, 0.f, 0.f, 0.f}, pv[32];            // pv: t = s * sl2 - m, then p = exp2(t), of the half that is being exponentiated
     constexpr float RESCALE_LAG = 8.f;
 
     // ---- VALU pieces, each placed behind one MFMA: volatile asm statements, one instruction each (compiler-visible arithmetic did not
@@ -208,48 +225,34 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnParams P) {
             unsigned w; a_cvt_pk(w, pv[j], pv[j + 1]); pf[qs][kbl * 2 + (r >> 1)] = w;
         }
     };
-    // row maxima of one half, 32 pieces k = 0 .. 31 (one per MFMA gap):
-    //   k < 16: the per-lane v_max3 chains, query block k >> 2;  k >= 16: the cross-row part of query blocks (0, 1) then (2, 3), the two
-    //   chains of a pair interleaved (each instruction's operands are two instructions old), ending in cand = ceil(max * sl2)
+    // Row maxima of one half, 16 pieces (one v_max3 each, query block k >> 2): only the LANE's eight scores are reduced.  A row needs a new
+    // maximum only when some score outgrows the stored one by more than 2^RESCALE_LAG, and that is a per-lane test against
+    // thr = (m + RESCALE_LAG) / sl2 in raw-score units -- the cross-row reduction, the candidate and the rescale run in the rare branch.
     bool need;
-    float cand[4], my[4];
+    float thr[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};        // m = -inf: the first half always takes the branch
     auto max_piece = [&](f32x4 (&s)[4][2], auto kt) __attribute__((always_inline)) {
-        constexpr int k = decltype(kt)::value;
-        if constexpr (k < 16) {
-            constexpr int qs = k >> 2, u = k & 3;
-            if constexpr (u == 0) mx[qs] = max3_asm(s[qs][0][0], s[qs][0][1], s[qs][0][2]);
-            if constexpr (u == 1) mx[qs] = max3_asm(mx[qs], s[qs][0][3], s[qs][1][0]);
-            if constexpr (u == 2) mx[qs] = max3_asm(mx[qs], s[qs][1][1], s[qs][1][2]);
-            if constexpr (u == 3) mx[qs] = max3_asm(mx[qs], s[qs][1][3], s[qs][1][3]);
-        } else {
-            constexpr int pr = (k - 16) >> 3, st = (k - 16) & 7, qa = 2 * pr, qb = 2 * pr + 1;
-            if constexpr (st == 0) { a_mov(my[qa], mx[qa]); a_mov(my[qb], mx[qb]); }
-            if constexpr (st == 1) { a_swap16(mx[qa], my[qa]); a_swap16(mx[qb], my[qb]); }
-            if constexpr (st == 2) { a_max(mx[qa], my[qa]); a_max(mx[qb], my[qb]); }
-            if constexpr (st == 3) { a_mov(my[qa], mx[qa]); a_mov(my[qb], mx[qb]); }
-            if constexpr (st == 4) { a_swap32(mx[qa], my[qa]); a_swap32(mx[qb], my[qb]); }
-            if constexpr (st == 5) { a_max(mx[qa], my[qa]); a_max(mx[qb], my[qb]); }
-            if constexpr (st == 6) { a_mulk(mx[qa], sl2); a_mulk(mx[qb], sl2); }          // scale > 0: the maximum commutes with the scaling
-            if constexpr (st == 7) {
-                a_ceil(cand[qa], mx[qa]); a_ceil(cand[qb], mx[qb]);
-                need |= (cand[qa] > m[qa] + RESCALE_LAG) | (cand[qb] > m[qb] + RESCALE_LAG);      // m = -inf before the first tile
-            }
-        }
+        constexpr int k = decltype(kt)::value, qs = k >> 2, u = k & 3;
+        if constexpr (u == 0) mx[qs] = max3_asm(s[qs][0][0], s[qs][0][1], s[qs][0][2]);
+        if constexpr (u == 1) mx[qs] = max3_asm(mx[qs], s[qs][0][3], s[qs][1][0]);
+        if constexpr (u == 2) mx[qs] = max3_asm(mx[qs], s[qs][1][1], s[qs][1][2]);
+        if constexpr (u == 3) { mx[qs] = max3_asm(mx[qs], s[qs][1][3], s[qs][1][3]); need |= mx[qs] > thr[qs]; }
     };
     auto decide = [&]() __attribute__((always_inline)) {
         if (__builtin_amdgcn_ballot_w64(need) != 0) {           // wave-uniform, rare after the first tile
+            float alpha[4];
             sfor<4>([&](auto qt) __attribute__((always_inline)) {
                 constexpr int qs = decltype(qt)::value;
-                const float mnew = fmaxf(m[qs], cand[qs]);
-                const float alpha = fexp2(m[qs] - mnew);        // 2^(integer) or 0
-                l[qs] *= alpha;
+                const float cand = ceilf(xrow_max(mx[qs]) * sl2);   // scale > 0: the maximum commutes with the scaling
+                const float mnew = fmaxf(m[qs], cand);
+                alpha[qs] = fexp2(m[qs] - mnew);                    // 2^(integer) or 0 (m = -inf before the first tile)
+                l[qs] *= alpha[qs];
                 m[qs] = mnew;
-                cand[qs] = alpha;
+                thr[qs] = (mnew + RESCALE_LAG) * inv_sl2;
             });
             mfma_settle();                                      // the slot's last P V MFMAs have written O
             sfor<128>([&](auto it) __attribute__((always_inline)) {
                 constexpr int a = decltype(it)::value;
-                acc_write<a>(fbits(acc_read<a>() * cand[a >> 5]));
+                acc_write<a>(fbits(acc_read<a>() * alpha[a >> 5]));
             });
             asm volatile("s_nop 3" ::: "memory");              // v_accvgpr_write -> MFMA reading it as C
         }
@@ -263,6 +266,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnParams P) {
         });
     };
 
+#ifdef RV_W64_STAMPS
+    long long w_dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long w_start = __builtin_readcyclecounter();
+    W_T0();
+#endif
     // ---- one tile: the stream of MFMA groups with the fragment reads FW_AHEAD groups ahead
     auto body = [&](int t, auto first_tag) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
@@ -286,8 +294,13 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnParams P) {
                 // between slots 2 and 3: the V column addresses move on to this tile's stage; the V pieces of tile t + 2 are issued
                 const int dcol = ((t & 3) == 0 && t > 0) ? -3 * W_TILE : W_TILE;
                 sfor<8>([&](auto dt) __attribute__((always_inline)) { acol[decltype(dt)::value] += dcol; });
-                if (t + 2 < ntiles) stage_v(t + 2);
             }
+            // the 8 staging pieces of tile t + 2 go out two at a time behind the P V slots' MFMA groups (light VALU there); a first tile
+            // has no slot 2: its K pieces ride in slot 3
+            if constexpr ((!FIRST && (G == 9 || G == 13)) || (FIRST && (G == 17 || G == 21)))
+                if (t + 2 < ntiles) stage_k(t + 2, ((G >> 2) & 1) ? 2 : 0, 2);
+            if constexpr (G == 25 || G == 29)
+                if (t + 2 < ntiles) stage_v(t + 2, G == 29 ? 2 : 0, 2);
             if constexpr (G == 8 || G == 24) {
                 if (edge) { mfma_settle(); mask_half(G == 8 ? s0 : s1, kv0 + (G == 8 ? 0 : 32)); }
                 if constexpr (G == 24 || !FIRST) need = false;
@@ -307,14 +320,14 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnParams P) {
                     if constexpr (!FIRST) exp_step(s1, std::integral_constant<int, G * 4 + u + 1>{});
                 } else if constexpr (G < 16) {
                     mfma_acc<fw_oa(u, G - 8)>(tf_get(vq[i & 3]), __builtin_bit_cast(bf16x8, pf[u]));
-                    max_piece(s0, std::integral_constant<int, (G - 8) * 4 + u>{});
+                    if constexpr (G < 12) max_piece(s0, std::integral_constant<int, (G - 8) * 4 + u>{});
                 } else if constexpr (G < 24) {
                     constexpr int kbl = (G - 16) >> 2, ks = G & 3;
                     if constexpr (ks == 0) mfma_s0<fw_qa(u, ks)>(s1[u][kbl], kq[i & 3]); else mfma_s<fw_qa(u, ks)>(s1[u][kbl], kq[i & 3]);
                     exp_step(s0, std::integral_constant<int, (G - 16) * 4 + u + 1>{});
                 } else {
                     mfma_acc<fw_oa(u, G - 24)>(tf_get(vq[i & 3]), __builtin_bit_cast(bf16x8, pf[u]));
-                    max_piece(s1, std::integral_constant<int, (G - 24) * 4 + u>{});
+                    if constexpr (G < 28) max_piece(s1, std::integral_constant<int, (G - 24) * 4 + u>{});
                 }
             });
             if constexpr (G == 7 && !FIRST) exp_step(s1, std::integral_constant<int, 33>{});
@@ -324,10 +337,14 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnParams P) {
                 // score MFMA and the asm maximum that reads its result: the hazard recogniser does not look into inline asm)
                 mfma_settle();
                 if (edge) mask_half(s0, kv0);
-                sfor<32>([&](auto kt) __attribute__((always_inline)) { max_piece(s0, kt); });
+                sfor<16>([&](auto kt) __attribute__((always_inline)) { max_piece(s0, kt); });
                 decide();
             }
             if constexpr (G == 15 || G == 31) decide();
+            if constexpr (G == 7) W_ACC(1);
+            if constexpr (G == 15) W_ACC(2);
+            if constexpr (G == 23) W_ACC(3);
+            if constexpr (G == 31) W_ACC(4);
         });
         // K row addresses -> next tile's stage
         const int drow = ((t & 3) == 3) ? -3 * W_TILE : W_TILE;
@@ -346,21 +363,41 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_w64_kernel(AttnParams P) {
     };
 
     for (int t = 0; t < ntiles; ++t) {
+#ifndef RV_W64_EXP
+#define RV_W64_EXP 0     // timing experiments only (wrong results): 1 no barrier, 2 no barrier + no staging waits, 3 zero-record staging descriptors, 4 no staging
+#endif
+#if RV_W64_EXP != 2 && RV_W64_EXP != 4
         if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // tile t landed; tile t + 1 (8 pieces) stays in flight
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#if RV_W64_EXP == 0 || RV_W64_EXP == 3
         __builtin_amdgcn_s_barrier();
-        // every wave has left tile t - 1: stage (t + 2) & 3 (tile t - 2's images) is free
-        if (t + 2 < ntiles) stage_k(t + 2);
+#endif
+        W_ACC(0);
+        // every wave has left tile t - 1: stage (t + 2) & 3 (tile t - 2's images) is free from here on
+        W_ACC(5);
+#ifdef RV_W64_STAMPS
+        if (t <= t_last) w_dbg[7] += 1;
+#endif
         if (t <= t_last) {
             if (t == 0) body(t, std::true_type{});
             else body(t, std::false_type{});
         } else {
-            if (t + 2 < ntiles) stage_v(t + 2);
+            if (t + 2 < ntiles) { stage_k(t + 2); stage_v(t + 2); }
             if (t == t_last + 1 && t_last >= 0) drain();
+            W_ACC(6);
         }
     }
     if (t_last >= 0 && t_last == ntiles - 1) drain();
 
+#ifdef RV_W64_STAMPS
+    if (P.delta && lane == 0) {
+        const long long tot = __builtin_readcyclecounter() - w_start;
+        const long blk = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
+        long long* o_ = (long long*)P.delta + (blk * 4 + wid) * 8;
+        for (int i = 0; i < 8; ++i) o_[i] = i == 6 ? tot : w_dbg[i];
+    }
+#endif
     // ---- epilogue: O / l, 16-byte stores (two 16-dim blocks exchanged between the wave's 16-lane rows: 8 consecutive dims per lane)
     mfma_settle();
     sfor<4>([&](auto qt) __attribute__((always_inline)) {

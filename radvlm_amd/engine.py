@@ -34,10 +34,12 @@ class LlavaEngine:
     def __init__(self, geo, device="cuda", merge_type="flat", image_aspect_ratio="square", image_grid_pinpoints=None,
                  max_len=None, init="portable", seed=0, rms_eps=1e-5, rope_theta=10000.0, process_group=None,
                  bucket_layers=1, train_vision_tower=False, lora=None, packed="auto", freeze_lm=False, train_embed_tokens=False,
+                 freeze_projector=False,
                  padding_side="right", force_grad_sync=False, recompute=False):
         self.geo = geo
         assert recompute in (False, True, "auto")
         self.recompute = recompute            # activation recompute policy of the decoder layers (_recompute_layers)
+        self._recompute_cache, self._recompute_forced = {}, False
         # packed (varlen) decoder batches: True / False / "auto" (pack when the samples of a batch differ in length): the decoder
         # then runs on sum(len_b) token rows instead of B * max(len_b) -- no padding rows through GEMMs, norms, CE
         self.packed = packed
@@ -86,16 +88,18 @@ class LlavaEngine:
         elif freeze_lm:
             # projector-only stage (tune_mm_mlp_adapter / mm_tunable_parts="mm_mlp_adapter", train/train.py:1613-1640): tower and
             # language model are frozen stores; the trainable flat buffer holds the projector (+ image_newline) alone -- the
-            # backward computes input gradients through the frozen decoder and no weight gradients for it
-            assert not train_vision_tower
+            # backward computes input gradients through the frozen decoder and no weight gradients for it.  With train_vision_tower
+            # (mm_tunable_parts="mm_vision_tower,mm_mlp_adapter": tower + projector, frozen LM) the tower joins that buffer, in front.
             from collections import OrderedDict
             full = lm_param_shapes(geo, self.with_newline)
             self.base = FlatParams(lm_param_shapes(geo, False), self.device)
             # train_embed_tokens: tune_mm_mlp_adapter + mm_use_im_start_end makes the INPUT embeddings trainable as well
             # (llava_arch.py:577-581: get_input_embeddings requires_grad True, get_output_embeddings False)
             keep = lambda k: "mm_projector" in k or k == "model.image_newline" or (train_embed_tokens and k == "model.embed_tokens.weight")
-            self.lm = FlatParams(OrderedDict((k, v) for k, v in full.items() if keep(k)), self.device)
-            self.vis = FlatParams(vision_param_shapes(geo), self.device)
+            shapes = OrderedDict(vision_param_shapes(geo)) if train_vision_tower else OrderedDict()
+            shapes.update((k, v) for k, v in full.items() if keep(k))
+            self.lm = FlatParams(shapes, self.device)
+            self.vis = self.lm if train_vision_tower else FlatParams(vision_param_shapes(geo), self.device)
         elif train_vision_tower:
             # mm_tunable_parts contains mm_vision_tower (train/train.py:1658-1661): the tower joins the trainable flat
             # buffer, in front (forward order), so its gradients are the last bucket of the backward pass
@@ -107,6 +111,17 @@ class LlavaEngine:
         else:
             self.lm = FlatParams(lm_param_shapes(geo, self.with_newline), self.device)
             self.vis = FlatParams(vision_param_shapes(geo), self.device)
+        # Tensors of the trainable buffer that stay FROZEN (any subset of mm_tunable_parts, train/train.py:1613-1665): their gradients are
+        # still computed where a kernel produces them anyway, then zeroed before the norm / clip, and AdamW skips them.
+        #   * mm_mlp_adapter absent  -> the projector;
+        #   * mm_language_model absent -> image_newline too (a parameter of the LM group there: no 'mm_projector' / 'vision_tower' in its name)
+        self.frozen_names = set()
+        if freeze_projector:
+            self.frozen_names |= {n for n in self.lm.names() if "mm_projector" in n}
+        if self.freeze_lm and "model.image_newline" in self.lm.offsets:
+            self.frozen_names.add("model.image_newline")
+        if not [n for n in self.lm.names() if n not in self.frozen_names]:
+            raise ValueError("nothing is trainable: mm_tunable_parts must name at least one of mm_vision_tower, mm_mlp_adapter, mm_language_model")
         self.grads = self.lm.like(BF16)
         stores = [self.lm] + ([] if train_vision_tower else [self.vis]) + ([self.base] if self.base is not None else [])
         for k, st in enumerate(stores):
@@ -526,7 +541,12 @@ class LlavaEngine:
     def activation_bytes_per_row(self):
         """bf16 bytes one decoder layer keeps per token row for backward: x, h1, q|k|v, attn, x_mid, h2, gate|up, act (+ fp32 statistics)."""
         d, F = self.l["d"], self.l["ffn"]
-        return 2 * (6 * d + 2 * self.kvd + 3 * F) + 4 * (2 + self.l["heads"])
+        n = 2 * (6 * d + 2 * self.kvd + 3 * F) + 4 * (2 + self.l["heads"])
+        if self.lora:                       # the seven adapted modules keep their r-wide down-projections
+            n += 2 * 7 * self.lora["r"]
+        if self.hd != 128:                  # head_dim 64 kernels read a V^T copy
+            n += 2 * self.kvd
+        return n
 
     def _recompute_layers(self, M):
         """How many decoder layers (the first n) re-run their forward in backward.  False: none -- the activations of all layers stay
@@ -538,13 +558,19 @@ class LlavaEngine:
             return L
         if not self.recompute or self.device.type != "cuda":
             return 0
+        if self._recompute_forced:           # a step ran out of memory under "auto": the retry (and the same shape later) keeps layer inputs only
+            return L
+        hit = self._recompute_cache.get(M)
+        if hit is not None:
+            return hit
         per_layer = M * self.activation_bytes_per_row()
         free, _ = torch.cuda.mem_get_info(self.device)
         free += torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)     # torch's cached, unused blocks
         # head room: logits (bf16 + dlogits in place) + the lm_head input gradient, one layer's recomputed activations and gradients
         budget = 0.85 * free - (4 * M * self.l["vocab"] + 3 * per_layer)
         keep = int(max(0.0, budget) // max(per_layer + 2 * M * self.l["d"], 1))
-        return max(0, L - keep)
+        self._recompute_cache[M] = max(0, L - keep)     # one decision per row count: later steps see less free memory only because of this one's caches
+        return self._recompute_cache[M]
 
     def _layer_forward(self, i, x, g):
         """One decoder layer (modeling_llama.py:852-911) on token rows x -> (x_out, the activations backward needs)."""
@@ -684,6 +710,62 @@ class LlavaEngine:
         self.ctx = ctx
         self.last_logits = logits_out
         return loss
+
+    def forward_embeds(self, inputs_embeds, attention_mask=None, labels=None):
+        """The decoder + head on caller-supplied input embeddings -- the call form of LlavaLlamaForCausalLM.forward with `inputs_embeds`
+        given (llava_llama.py:69-120: the multimodal splice is skipped and super().forward runs on the embeddings; what generate() and
+        eval-loss loops use).  inputs_embeds [B, S, d]; attention_mask [B, S] (None = all valid; right or left padded); labels [B, S] or
+        None.  Returns (loss or None, fp32 logits [B, S, vocab]); nothing is kept for a backward pass."""
+        dev, l = self.device, self.l
+        d, V, L = l["d"], l["vocab"], l["layers"]
+        x3 = torch.as_tensor(inputs_embeds)
+        B, S = int(x3.shape[0]), int(x3.shape[1])
+        assert x3.shape[2] == d, f"inputs_embeds last dimension {x3.shape[2]} != hidden size {d}"
+        am = np.ones((B, S), dtype=bool) if attention_mask is None else np.asarray(torch.as_tensor(attention_mask).cpu()).astype(bool)
+        lens_np = am.sum(1).astype(np.int32)
+        right_padded = all(am[b, :lens_np[b]].all() for b in range(B))
+        x = x3.to(dev).reshape(B * S, d)
+        x = (x if x.dtype == BF16 else ops.to_bf16(x.float().contiguous())).contiguous()
+        s_pad = _ru(S, 64)
+        cu = pos = valid_idx = lens = None
+        if right_padded:
+            M, lens = B * S, self._dev(lens_np)
+        else:   # any other mask: valid tokens only, positions = padded column index (HF: position_ids = arange(S) when none are passed)
+            valid = am.reshape(-1)
+            valid_idx = np.nonzero(valid)[0]
+            M = int(valid.sum())
+            cu = self._dev(np.concatenate([[0], np.cumsum(lens_np)]).astype(np.int32))
+            pos = self._dev((np.arange(B * S, dtype=np.int32) % S)[valid])
+            x = x[self._dev(valid_idx.astype(np.int64))].contiguous()
+        geom = dict(B=B, S=S, s_pad=s_pad, lens=lens, cu=cu, pos=pos, cs=self.rope_table(S))
+        saved = (self.lora_step, getattr(self, "lora_p", 0.0))
+        self.lora_p = 0.0                    # eval form: the adapters' input dropout is off (module.eval() in the reference)
+        try:
+            for i in range(L):
+                x, _ = self._layer_forward(i, x, geom)
+        finally:
+            self.lora_step, self.lora_p = saved
+        hN, _ = ops.rmsnorm_fwd(x, self.W("model.norm.weight"), self.eps)
+        lf = ops.gemm_nt(hN, self.W("lm_head.weight"), out_dtype=torch.float32)
+        if valid_idx is not None:
+            full = torch.zeros(B * S, lf.shape[1], dtype=torch.float32, device=dev)
+            full[self._dev(valid_idx.astype(np.int64))] = lf
+            lf = full
+        logits = lf.view(B, S, -1)[..., :self.vocab]
+        loss = None
+        if labels is not None:
+            lab = np.asarray(torch.as_tensor(labels).cpu()).astype(np.int64)
+            tgt = shifted_labels(np.where(am, lab, -100))
+            if tgt.size and int(tgt.max()) >= self.vocab:
+                raise IndexError(f"label {int(tgt.max())} is out of range for a vocabulary of {self.vocab}")
+            count = int((tgt != -100).sum())
+            tgt = tgt.reshape(-1)
+            if valid_idx is not None:
+                tgt = tgt[valid_idx]
+            logits_bf = ops.gemm_nt(hN, self.W("lm_head.weight"))     # the loss reads bf16 logits, as the training path does
+            loss, _ = self._cross_entropy(logits_bf, self._dev(tgt), self.vocab, (1.0 / count) if count else float("nan"), 0.0)
+        self.last_logits = logits
+        return loss, logits
 
     def _cross_entropy(self, logits, tgt, V, inv, gscale):
         from . import lib
@@ -903,6 +985,32 @@ class LlavaEngine:
     def zero_grad(self):
         self.grad_accum_started = False
 
+    def _replica_buffers(self):
+        bufs = [("parameters", self.lm.flat)]
+        if self.vis is not self.lm:
+            bufs.append(("vision_tower", self.vis.flat))
+        if self.base is not None:
+            bufs.append(("frozen_language_model", self.base.flat))
+        return bufs + [("fp32_master", self.master), ("exp_avg", self.m), ("exp_avg_sq", self.vv)]
+
+    def broadcast_parameters(self):
+        """Rank 0's parameters (and optimizer state, once it exists) become every rank's: the broadcast DistributedDataParallel performs
+        when it wraps the model (HF Trainer / accelerate in the reference).  No-op for one rank."""
+        if self.world > 1:
+            from .ddp import broadcast_from_rank0
+            broadcast_from_rank0(self._replica_buffers(), self.pg)
+            self.weights_changed(tower=True)
+
+    def check_replicas(self, where=""):
+        """Raise unless every rank holds bit-identical parameters, frozen stores and optimizer state (all-reduced checksums)."""
+        if self.world > 1:
+            from .ddp import assert_replicas_equal
+            assert_replicas_equal(self._replica_buffers(), self.pg, where)
+
+    def barrier(self):
+        if self.world > 1:
+            torch.distributed.barrier(group=self.pg)
+
     # ------------------------------------------------------------------ optimizer
     def init_optimizer(self):
         if self.master is None:
@@ -914,7 +1022,12 @@ class LlavaEngine:
         """Contiguous (start, end, lr, wd) slices following LLaVATrainer.create_optimizer (llava_trainer.py:369-418):
         no weight decay for norm weights and biases; optional separate LR for the projector."""
         groups = []
+        fresh = True             # a frozen tensor in between: the next group must not be merged across its slice
+        frozen = getattr(self, "frozen_names", ())
         for name in self.lm.names():
+            if name in frozen:
+                fresh = True
+                continue
             off, n = self.lm.offsets[name]
             shp = self.lm.shapes[name]
             nodecay = no_decay_1d and (len(shp) == 1 and ("norm" in name or name.endswith("bias")))
@@ -922,10 +1035,11 @@ class LlavaEngine:
             if mm_vision_tower_lr is not None and "vision_tower" in name:
                 glr = mm_vision_tower_lr
             gwd = 0.0 if nodecay else weight_decay
-            if groups and groups[-1][2] == glr and groups[-1][3] == gwd and groups[-1][1] <= off:
+            if groups and not fresh and groups[-1][2] == glr and groups[-1][3] == gwd and groups[-1][1] <= off:
                 groups[-1][1] = off + n  # merge (alignment gaps hold zeros and stay zero)
             else:
                 groups.append([off, off + n, glr, gwd])
+            fresh = False
         return [tuple(g) for g in groups]
 
     def optimizer_step(self, lr, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=None, mm_projector_lr=None,
@@ -936,6 +1050,8 @@ class LlavaEngine:
         self.opt_step += 1
         coef = None
         self.last_grad_norm = None
+        for name in self.frozen_names:          # frozen tensors of the buffer take no part in the gradient norm
+            self.G(name).zero_()
         if max_grad_norm is not None and max_grad_norm > 0:
             nc = ops.grad_norm_clip_coef(self.grads, max_grad_norm)
             self.last_grad_norm = nc[0:1]

@@ -10,6 +10,7 @@ backward (one autograd node for the whole step), so an HF-Trainer-style ``traini
 import os
 from types import SimpleNamespace
 
+import numpy as np
 import torch
 
 from ...engine import LlavaEngine
@@ -147,6 +148,7 @@ class LlavaLlamaForCausalLM:
                                   train_vision_tower=getattr(config, "unfreeze_mm_vision_tower", False),
                                   lora=getattr(config, "lora", None), freeze_lm=getattr(config, "freeze_lm", False),
                                   train_embed_tokens=getattr(config, "train_embed_tokens", False),
+                                  freeze_projector=getattr(config, "freeze_mm_mlp_adapter", False),
                                   padding_side=getattr(config, "tokenizer_padding_side", "right"),
                                   recompute=getattr(config, "activation_recompute", False))
         self.model = self.model_class(self.engine, config)
@@ -160,8 +162,11 @@ class LlavaLlamaForCausalLM:
 
     def gradient_checkpointing_enable(self, gradient_checkpointing_kwargs=None):
         """HF PreTrainedModel.gradient_checkpointing_enable (what Trainer calls for --gradient_checkpointing, reference
-        train/train.py:1505-1513): every decoder layer keeps only its input and re-runs its forward in backward."""
-        self.engine.recompute = True
+        train/train.py:1505-1513).  The reference re-runs EVERY decoder layer's forward in backward; here the flag selects the engine's
+        "auto" policy -- the first n layers are recomputed, n taken per batch from free HBM (0 for the BASELINE batch on 288 GB), with
+        bit-identical gradients either way.  LlavaEngine(recompute=True) is the explicit recompute-everything switch."""
+        if self.engine.recompute is not True:
+            self.engine.recompute = "auto"
         self.is_gradient_checkpointing = True
 
     def gradient_checkpointing_disable(self):
@@ -232,15 +237,24 @@ class LlavaLlamaForCausalLM:
     def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None, labels=None,
                 use_cache=None, output_attentions=None, output_hidden_states=None, images=None, image_sizes=None, return_dict=None,
                 modalities=("image",), dpo_forward=None, cache_position=None, output_logits=None):
-        if inputs_embeds is not None or past_key_values is not None or dpo_forward:
-            raise NotImplementedError("only the training call form (input_ids + images + labels) is on the hot path")
+        if past_key_values is not None or dpo_forward:
+            raise NotImplementedError("key/value caches and the DPO forward are serving / preference-tuning paths (SURVEY section 2: out of scope)")
+        if inputs_embeds is not None:
+            # llava_llama.py:83-120 with inputs_embeds given: no multimodal splice, the decoder runs on the embeddings (eval loss, the
+            # per-step call of a generation loop without cache); fp32 logits, loss when labels are passed; no backward
+            if input_ids is not None:
+                raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
+            loss, logits = self.engine.forward_embeds(inputs_embeds, attention_mask=attention_mask, labels=labels)
+            return CausalLMOutputWithPast(loss=loss, logits=logits)
         if images is None:
             raise ValueError("images is required (text-only samples carry a dummy zero image, train.py:1227-1232)")
         imgs = list(images) if not torch.is_tensor(images) else [im for im in images]
         ids = input_ids.cpu().numpy() if torch.is_tensor(input_ids) else input_ids
         am = attention_mask.cpu().numpy() if torch.is_tensor(attention_mask) else attention_mask
         lab = labels.cpu().numpy() if torch.is_tensor(labels) else labels
-        want_logits = (not self.training) if output_logits is None else output_logits
+        if lab is None:          # labels=None (llava_llama.py:69-120 returns logits only): nothing to score
+            lab = np.full(np.asarray(ids).shape, -100, dtype=np.int64)
+        want_logits = (labels is None or not self.training) if output_logits is None else output_logits
         loss = self.engine.forward(ids, am, lab, imgs, image_sizes=image_sizes, want_logits=want_logits)
         if self.training and labels is not None:
             loss = _StepFunction.apply(self._anchor, self.engine, loss)

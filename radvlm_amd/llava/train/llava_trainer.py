@@ -175,16 +175,19 @@ def lr_at(update, total_steps, base_lr, warmup_steps, kind="cosine"):
     raise ValueError(f"lr_scheduler_type {kind!r}: cosine, linear, constant and constant_with_warmup are built")
 
 
-def epoch_index_batches(n, sampler, seed, per_device_batch, world, rank, accum):
+def epoch_index_batches(n, sampler, seed, per_device_batch, world, rank, accum, drop_last=True):
     """The stream of per-rank micro-batches (lists of dataset indices), epoch after epoch, without end.
 
     Every epoch draws a fresh order -- `iter(sampler)` on a sampler whose generator was seeded once (what re-iterating the
     DataLoader does in HF Trainer), or a seeded permutation without a sampler -- and is consumed whole: the r-th
     `per_device_batch` slice of every world batch belongs to rank r (accelerate's batch sharding of the grouped order,
     llava_trainer.py:129-149), an incomplete last world batch and the micro-batches that do not fill a last optimizer step
-    are dropped.  Returns (generator, optimizer steps per epoch)."""
+    are dropped.  drop_last=False (--dataloader_drop_last False, the HF default; llava_trainer.py:348): the incomplete last world
+    batch is completed with samples from the head of the same epoch's order, as accelerate's even_batches sharding does, instead of
+    being dropped.  Returns (generator, optimizer steps per epoch)."""
     wb = per_device_batch * world
-    steps_per_epoch = (n // wb) // accum
+    world_batches = n // wb if drop_last else -(-n // wb)
+    steps_per_epoch = world_batches // accum
     if steps_per_epoch < 1:
         raise ValueError(f"{n} samples do not fill one optimizer step of {wb} x {accum}")
     g = torch.Generator().manual_seed(seed)
@@ -192,6 +195,8 @@ def epoch_index_batches(n, sampler, seed, per_device_batch, world, rank, accum):
     def gen():
         while True:
             order = list(iter(sampler)) if sampler is not None else torch.randperm(n, generator=g).tolist()
+            if not drop_last and len(order) % wb:
+                order = order + order[:wb - len(order) % wb]
             mine = shard_for_rank(order, per_device_batch, world, rank)
             for j in range(steps_per_epoch * accum):
                 yield mine[j * per_device_batch:(j + 1) * per_device_batch]
@@ -300,7 +305,8 @@ class LLaVATrainer:
         eng = self.model.engine
         world, rank = getattr(a, "world_size", 1), getattr(a, "process_index", 0)
         bs, accum = a.per_device_train_batch_size, max(1, int(getattr(a, "gradient_accumulation_steps", 1) or 1))
-        it, steps_per_epoch = epoch_index_batches(len(self.train_dataset), self._get_train_sampler(), getattr(a, "seed", 42), bs, world, rank, accum)
+        it, steps_per_epoch = epoch_index_batches(len(self.train_dataset), self._get_train_sampler(), getattr(a, "seed", 42), bs, world, rank, accum,
+                                                  drop_last=bool(getattr(a, "dataloader_drop_last", False)))
         max_steps = int(getattr(a, "max_steps", -1) or -1)
         total = max_steps if max_steps > 0 else math.ceil(steps_per_epoch * float(a.num_train_epochs))
         warm = warmup_steps_for(a, total)
@@ -308,6 +314,7 @@ class LLaVATrainer:
         kind = getattr(kind, "value", kind)
 
         start = self._maybe_resume(resume_from_checkpoint)
+        eng.check_replicas("start of training")       # after init / load / resume: every rank holds the same parameters and optimizer state
         for _ in range(start * accum):       # a resumed run continues the same sample stream (epoch orders are regenerated from the seed)
             next(it)
         loader = BatchPrefetcher(self.train_dataset, self.data_collator, (next(it) for _ in range((total - start) * accum)),
@@ -326,8 +333,23 @@ class LLaVATrainer:
                     batch = next(loader)
                     t_data += time.perf_counter() - td
                     eng.sync_this_backward = micro == accum - 1
-                    out = self.model(**batch)
-                    out.loss.backward()
+                    try:
+                        out = self.model(**batch)
+                        out.loss.backward()
+                    except torch.cuda.OutOfMemoryError:
+                        # the "auto" recompute policy sized this batch from an estimate of free memory (fragmented cache blocks count as
+                        # free): retry once with every layer recomputed.  Only the first micro-batch of a step can be redone -- later ones
+                        # have already accumulated part of their gradients.
+                        if micro > 0 or eng.recompute != "auto" or eng._recompute_forced or eng.sync is not None:
+                            raise
+                        eng._recompute_forced = True
+                        eng.ctx = None
+                        eng.grad_accum_started = False
+                        torch.cuda.empty_cache()
+                        if rank == 0:
+                            print("[train] out of device memory under recompute='auto': retrying the step with every decoder layer recomputed", flush=True)
+                        out = self.model(**batch)
+                        out.loss.backward()
                     losses.append(out.loss)
                 lr = lr_at(step, total, a.learning_rate, warm, kind)
                 scale = lr / a.learning_rate if a.learning_rate else 0.0      # the per-module rates follow the same schedule
@@ -345,7 +367,12 @@ class LLaVATrainer:
                     if rank == 0:
                         print(rec, flush=True)
                 if save_steps and step % save_steps == 0 and getattr(a, "output_dir", None):
+                    eng.check_replicas(f"step {step}")
                     self.save_checkpoint(os.path.join(a.output_dir, f"checkpoint-{step}"), rank)
+                    self._rotate_checkpoints(a.output_dir, rank)
+                    # the other ranks wait here while rank 0 writes (a 7B checkpoint with optimizer state is ~95 GB): no rank runs ahead
+                    # into the next step's collectives, a resumed run never sees a half-written directory as the newest checkpoint
+                    eng.barrier()
         finally:
             eng.loss_scale = 1.0
             loader.close()
@@ -387,6 +414,19 @@ class LLaVATrainer:
         with open(os.path.join(path, "trainer_state.json"), "w") as f:
             json.dump({"global_step": self.state["global_step"], "opt_step": eng.opt_step, "lora_step": eng.lora_step,
                        "log_history": self.state["log_history"]}, f)
+
+    def _rotate_checkpoints(self, output_dir, rank=0):
+        """--save_total_limit N (HF Trainer._rotate_checkpoints; finetune_radio_7b.sh:72 passes 1): keep the N newest checkpoint-* directories
+        of output_dir, delete the older ones (13.5 + 81 GB each for the 7B model: an ignored limit fills the disk)."""
+        limit = getattr(self.args, "save_total_limit", None)
+        if rank != 0 or not limit or limit <= 0:
+            return []
+        import shutil
+        cands = sorted((d for d in os.listdir(output_dir) if d.startswith("checkpoint-") and d[11:].isdigit()), key=lambda d: int(d[11:]))
+        doomed = cands[:-int(limit)]
+        for d in doomed:
+            shutil.rmtree(os.path.join(output_dir, d), ignore_errors=True)
+        return doomed
 
     def _maybe_resume(self, resume_from_checkpoint):
         """True -> newest checkpoint-* under output_dir (the reference's auto-resume, train.py:1699-1702); str -> that directory."""

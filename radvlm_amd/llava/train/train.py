@@ -546,12 +546,22 @@ def train(attn_implementation=None, argv=None, tokenizer=None):
     torch.cuda.set_device(local)
     pg = None
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # the reference lifts the collective timeout (llava_trainer.py:247-248, InitProcessGroupKwargs(timeout=timedelta(weeks=52))): rank 0
+        # writes checkpoints (13.5 GB of weights + 81 GB of optimizer state for the 7B model) while the other ranks wait in a collective
+        import datetime
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local),
+                                             timeout=datetime.timedelta(weeks=int(os.environ.get("RV_PG_TIMEOUT_WEEKS", 52))))
         pg = torch.distributed.group.WORLD
     parts = tunable_parts(model_args)
+    known = {"mm_mlp_adapter", "mm_language_model", "mm_vision_tower"}
+    if "mm_vision_resampler" in parts:
+        raise NotImplementedError("mm_vision_resampler: no resampler is on the hot path (SURVEY section 2: out of scope)")
+    if not parts & known:
+        raise ValueError(f"mm_tunable_parts {sorted(parts)}: nothing to train (expected a subset of {sorted(known)})")
+    # any subset of the three parts (train/train.py:1613-1665): the LM either lives in the trainable flat buffer or is a frozen store; the
+    # tower joins the buffer when tunable; a projector that is not named stays in the buffer but frozen
+    frozen_lm = "mm_language_model" not in parts
     projector_only = parts == {"mm_mlp_adapter"}      # tune_mm_mlp_adapter / mm_tunable_parts="mm_mlp_adapter": the pretraining stage
-    if not projector_only and parts - {"mm_vision_tower"} != {"mm_mlp_adapter", "mm_language_model"}:
-        raise NotImplementedError(f"tunable parts {sorted(parts)}: supported are projector only, projector + LM, projector + LM + tower")
     lora = None
     if training_args.lora_enable:   # peft LoraConfig(r, lora_alpha, lora_dropout, bias="none") on every LM linear (train.py:1515-1532)
         if training_args.lora_bias != "none" or "mm_vision_tower" in parts:
@@ -562,7 +572,8 @@ def train(attn_implementation=None, argv=None, tokenizer=None):
     cfg = Config(geometry=geometry, mm_patch_merge_type=model_args.mm_patch_merge_type,
                       image_aspect_ratio=data_args.image_aspect_ratio, image_grid_pinpoints=data_args.image_grid_pinpoints,
                       tokenizer_model_max_length=training_args.model_max_length,
-                      unfreeze_mm_vision_tower="mm_vision_tower" in parts, lora=lora, freeze_lm=projector_only,
+                      unfreeze_mm_vision_tower="mm_vision_tower" in parts, lora=lora, freeze_lm=frozen_lm and not lora,
+                      freeze_mm_mlp_adapter="mm_mlp_adapter" not in parts,
                       train_embed_tokens=projector_only and model_args.mm_use_im_start_end)
     cfg._name_or_path = model_args.model_name_or_path
     model = Model(cfg, device=f"cuda:{local}", process_group=pg, init="fast")
@@ -577,6 +588,9 @@ def train(attn_implementation=None, argv=None, tokenizer=None):
     if lm_dir:
         from ...checkpoint_io import load_pretrained
         load_pretrained(model.engine, lm_path=lm_dir, tower_path=tower_dir)     # raises if any LM / tower tensor is missing
+    # DDP broadcasts rank 0's parameters when it wraps the model (HF Trainer / accelerate): here every rank initialised or
+    # loaded its own copy -- one broadcast makes the replicas identical by construction, the check below proves it from then on
+    model.engine.broadcast_parameters()
     model.config.use_cache = False
     model.get_model().initialize_vision_modules(model_args)
     if model_args.version in conversation_lib.conv_templates:

@@ -372,7 +372,9 @@ def lora_down(x, a, alpha, p, seed, out=None):
     r <= 64); other shapes take the two-launch sequence."""
     M, K = x.shape
     r = a.shape[0]
-    if not ((x.is_contiguous() or (p <= 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0)) and K % 64 == 0 and r <= 64 and r % 4 == 0 and a.stride(1) == 1):
+    # rv_lora_down_bf16 takes 16-byte vector accesses: base pointers 16-byte aligned, adapter rows a multiple of 8 elements apart
+    if not ((x.is_contiguous() or (p <= 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0)) and K % 64 == 0 and r <= 64 and r % 4 == 0 and a.stride(1) == 1
+            and x.data_ptr() % 16 == 0 and a.data_ptr() % 16 == 0 and a.stride(0) % 8 == 0):
         return gemm(dropout(x.contiguous(), p, seed) if p > 0 else x, a, alpha=alpha, out=out)
     if out is None:
         out = torch.empty(M, r, dtype=BF16, device=x.device)
@@ -387,7 +389,7 @@ def gemm_dropout_add(a, b, y, p, seed, tb=True, alpha=1.0, accumulate=True):
     M, K = a.shape
     N = b.shape[1] if tb else b.shape[0]
     assert y.shape == (M, N) and (b.shape[0] if tb else b.shape[1]) == K and a.stride(1) == 1 and b.stride(1) == 1 and y.stride(1) == 1
-    if p <= 0 or N % 8 or y.stride(0) != N:       # the mask indexes y as M * N contiguous elements
+    if p <= 0 or N % 8 or y.stride(0) != N or y.data_ptr() % 16:       # the mask indexes y as M * N contiguous elements, 16-byte accesses
         t = gemm(a, b, tb=tb, alpha=alpha)
         return dropout_add(t, y, p, seed) if p > 0 else y.add_(t) if accumulate else y.copy_(t)
     lib.call("rv_gemm_dropout_add_bf16", a, a.stride(0), b, b.stride(0), y, y.stride(0), M, N, K, int(tb), float(alpha), float(p), int(seed),

@@ -78,6 +78,30 @@ allr = [torch.zeros_like(mine) for _ in range(world)]
 dist.all_gather(allr, mine)
 flat_all = torch.cat(allr).tolist()
 assert len(set(flat_all)) == len(flat_all) == 64
+# replica consistency (what DDP's wrap-time broadcast + nothing else gives the reference): identical buffers pass, one differing element
+# on one rank is caught on EVERY rank, a broadcast from rank 0 repairs it
+from radvlm_amd.ddp import assert_replicas_equal, broadcast_from_rank0
+w = torch.arange(5000, dtype=torch.float32).to(torch.bfloat16)
+st = torch.linspace(0, 1, 777)
+assert assert_replicas_equal([("parameters", w), ("absent", None), ("exp_avg", st)], None, "unit") == ["parameters", "exp_avg"]
+st2 = st.clone()
+if rank == 1:
+    st2[500] += 1e-3
+try:
+    assert_replicas_equal([("parameters", w), ("exp_avg", st2)], None, "after a faulty step")
+    raise SystemExit("divergence not detected")
+except RuntimeError as e:
+    assert "exp_avg" in str(e) and "parameters" not in str(e).split("differ")[0].split(":")[-1], str(e)
+swapped = w.clone()
+if rank == 1:
+    swapped[[10, 11]] = swapped[[11, 10]]         # same multiset of values: only the index-weighted sum sees it
+try:
+    assert_replicas_equal([("parameters", swapped)], None, "swap")
+    raise SystemExit("swap not detected")
+except RuntimeError:
+    pass
+broadcast_from_rank0([("exp_avg", st2), ("parameters", swapped)], None)
+assert_replicas_equal([("parameters", swapped), ("exp_avg", st2)], None, "after broadcast")
 dist.destroy_process_group()
 print("OK", rank)
 """

@@ -341,7 +341,12 @@ def test_dropin_radvlm_package_extends_instead_of_shadowing(tmp_path):
     (other / "radvlm" / "evaluation").mkdir()
     (other / "radvlm" / "__init__.py").write_text("raise RuntimeError('the stand-in package __init__ must not be needed')\n")
     (other / "radvlm" / "data" / "__init__.py").write_text("")
-    (other / "radvlm" / "data" / "datasets.py").write_text("MARK = 'datasets of the other tree'\n")
+    # like the reference's datasets.py:24 / :1088: names such as defaultdict reach it through the star import of create_instructions
+    (other / "radvlm" / "data" / "utils.py").write_text("def custom_collate_fn(batch):\n    return batch\n")
+    (other / "radvlm" / "data" / "datasets.py").write_text(
+        "from radvlm.data.create_instructions import *\nMARK = 'datasets of the other tree'\n"
+        "GROUPS = defaultdict(list)\nGROUPS['a'].append(Counter('aab')['a'] + int(np.int64(1)) + len(custom_collate_fn([1])))\n"
+        "assert DataLoader is not None and random.random() < 1 and GROUPS['a'] == [4]\n")
     (other / "radvlm" / "evaluation" / "__init__.py").write_text("MARK = 'evaluation of the other tree'\n")
     code = ("import radvlm.data.datasets as d, radvlm.evaluation as e, radvlm.data.create_instructions as c, radvlm.data as rd;"
             "from radvlm import DATA_DIR;"

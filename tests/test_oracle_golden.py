@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import llava_oracle as O
 from radvlm_amd.config import GEOMETRIES
@@ -308,3 +309,84 @@ def test_bf16_emulation_backward_reduces_to_autograd(kvh, bias):
     assert close(out["g_ln1"], P[pre + "input_layernorm.weight"].grad) and close(out["g_ln2"], P[pre + "post_attention_layernorm.weight"].grad)
     if bias:
         assert close(out["g_bqkv"], torch.cat([P[pre + f"self_attn.{n}_proj.bias"].grad for n in "qkv"], 0))
+
+
+@pytest.mark.parametrize("kind", ["clip", "siglip"])
+def test_bf16_emulation_tower_head_backward_reduces_to_autograd(kind):
+    """The hand-written derivatives of oracle/bf16_emulation.py for the rest of the trainable path -- one CLIP / SigLIP encoder layer,
+    the mlp2x_gelu projector, lm_head + cross entropy, the LoRA-adapted linear with its counter-based dropout mask -- with the rounding
+    switched off must equal torch autograd of their own forwards (which `vision_tower` / `mm_projector` / `llama_forward` run and
+    test_bf16_emulation_reduces_to_oracle pins to the reference-pinned oracle) to 1e-5."""
+    from oracle import bf16_emulation as E
+    g = torch.Generator().manual_seed(11)
+    close = lambda a, b, tol=1e-5: float((a - b).abs().max() / b.abs().max()) < tol
+    # ---- one tower layer
+    d, H, ffn, n, N = 48, 4, 80, 2, 19
+    v = dict(d=d, heads=H, ffn=ffn, kind=kind if kind == "siglip" else "clip")
+    p = E.VP + "encoder.layers.0."
+    shapes = {"layer_norm1.weight": (d,), "layer_norm1.bias": (d,), "layer_norm2.weight": (d,), "layer_norm2.bias": (d,),
+              "self_attn.q_proj.weight": (d, d), "self_attn.k_proj.weight": (d, d), "self_attn.v_proj.weight": (d, d), "self_attn.out_proj.weight": (d, d),
+              "self_attn.q_proj.bias": (d,), "self_attn.k_proj.bias": (d,), "self_attn.v_proj.bias": (d,), "self_attn.out_proj.bias": (d,),
+              "mlp.fc1.weight": (ffn, d), "mlp.fc1.bias": (ffn,), "mlp.fc2.weight": (d, ffn), "mlp.fc2.bias": (d,)}
+    P = {p + k: (torch.randn(*s, generator=g) * (0.25 if len(s) == 2 else 0.5) + (1.0 if k.endswith("norm1.weight") or k.endswith("norm2.weight") else 0.0)
+                 ).requires_grad_(True) for k, s in shapes.items()}
+    x = torch.randn(n, N, d, generator=g).requires_grad_(True)
+    dy = torch.randn(n, N, d, generator=g)
+    y, T = E.vision_layer(x, P, p, v, E.identity)
+    y.backward(dy)
+    out = E.vision_layer_backward({k: t.detach() for k, t in T.items()}, {k: t.detach() for k, t in P.items()}, p, v, dy, E.identity)
+    G = lambda name: P[p + name].grad
+    assert close(out["dx_in"], x.grad)
+    for key, name in (("gW_fc2", "mlp.fc2.weight"), ("g_fc2_b", "mlp.fc2.bias"), ("gW_fc1", "mlp.fc1.weight"), ("g_fc1_b", "mlp.fc1.bias"),
+                      ("g_ln2_w", "layer_norm2.weight"), ("g_ln2_b", "layer_norm2.bias"), ("gW_out", "self_attn.out_proj.weight"),
+                      ("g_out_b", "self_attn.out_proj.bias"), ("g_ln1_w", "layer_norm1.weight"), ("g_ln1_b", "layer_norm1.bias")):
+        assert close(out[key], G(name)), key
+    assert close(out["gW_qkv"], torch.cat([G(f"self_attn.{t}_proj.weight") for t in "qkv"], 0))
+    assert close(out["g_bqkv"], torch.cat([G(f"self_attn.{t}_proj.bias") for t in "qkv"], 0), 2e-5)      # the key bias gradient is ~0 (softmax shift invariance)
+    if kind == "siglip":
+        return
+    # ---- projector
+    dv, dl, rows = 48, 64, 37
+    Pp = {"model.mm_projector.0.weight": torch.randn(dl, dv, generator=g) * 0.2, "model.mm_projector.0.bias": torch.randn(dl, generator=g) * 0.1,
+          "model.mm_projector.2.weight": torch.randn(dl, dl, generator=g) * 0.2, "model.mm_projector.2.bias": torch.randn(dl, generator=g) * 0.1}
+    Pp = {k: t.requires_grad_(True) for k, t in Pp.items()}
+    f0 = torch.randn(rows, dv, generator=g).requires_grad_(True)
+    dproj = torch.randn(rows, dl, generator=g)
+    E.TRACE = {}
+    try:
+        proj = E.mm_projector(Pp, f0, E.identity)
+        Tp = E.TRACE
+    finally:
+        E.TRACE = None
+    proj.backward(dproj)
+    outp = E.mm_projector_backward(Tp, {k: t.detach() for k, t in Pp.items()}, dproj, E.identity)
+    assert close(outp["df0"], f0.grad)
+    for key, name in (("gW2", "model.mm_projector.2.weight"), ("g_b2", "model.mm_projector.2.bias"), ("gW0", "model.mm_projector.0.weight"),
+                      ("g_b0", "model.mm_projector.0.bias")):
+        assert close(outp[key], Pp[name].grad), key
+    # ---- lm_head + cross entropy (mean over the rows that carry a label, as modeling_llama.py:1332-1337)
+    V = 56
+    hN = torch.randn(2, 9, dl, generator=g).requires_grad_(True)
+    wh = (torch.randn(V, dl, generator=g) * 0.3).requires_grad_(True)
+    tg = torch.randint(0, V, (2, 9), generator=g)
+    tg[0, :3] = -100
+    tg[1, -1] = -100
+    loss = F.cross_entropy(F.linear(hN, wh).view(-1, V), tg.view(-1), ignore_index=-100)
+    loss.backward()
+    outh = E.lm_head_cross_entropy(hN.detach(), wh.detach(), tg, 1.0, E.identity)
+    assert abs(float(outh["loss"]) - float(loss)) < 1e-5 and close(outh["dhN"], hN.grad) and close(outh["gW_head"], wh.grad)
+    # ---- LoRA-adapted linear, with and without its dropout mask
+    for pdrop in (0.0, 0.25):
+        r, din, dout, seed = 8, 40, 24, 77
+        xl = torch.randn(3, 5, din, generator=g).requires_grad_(True)
+        Wl = torch.randn(dout, din, generator=g) * 0.2
+        A = (torch.randn(r, din, generator=g) * 0.3).requires_grad_(True)
+        Bm = (torch.randn(dout, r, generator=g) * 0.3).requires_grad_(True)
+        keep = E.dropout_keep_mask(xl.shape, pdrop, seed).float() if pdrop > 0 else torch.ones(3, 5, din)
+        assert pdrop == 0 or 0.6 < float(keep.mean()) < 0.9
+        yl = F.linear(xl, Wl) + F.linear(F.linear(xl * keep / (1.0 - pdrop), A), Bm) * 2.0
+        dyl = torch.randn(3, 5, dout, generator=g)
+        yl.backward(dyl)
+        y2, t = E.lora_linear(xl.detach(), Wl, A.detach(), Bm.detach(), 2.0, pdrop, seed, E.identity)
+        ob = E.lora_linear_backward(dyl, xl.detach(), Wl, A.detach(), Bm.detach(), t, 2.0, pdrop, seed, E.identity)
+        assert close(y2, yl.detach()) and close(ob["dx"], xl.grad) and close(ob["gA"], A.grad) and close(ob["gB"], Bm.grad)

@@ -391,3 +391,85 @@ def test_images_already_on_the_device(golden_dir):
     assert float(dev.loss) == l0
     dev.loss.backward()
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("parts", ["mm_vision_tower,mm_mlp_adapter", "mm_language_model", "mm_vision_tower", "mm_vision_tower,mm_language_model"])
+def test_every_subset_of_mm_tunable_parts(golden_dir, parts):
+    """mm_tunable_parts accepts ANY subset of tower / projector / language model (train/train.py:1613-1665: everything is frozen first,
+    then each named part is unfrozen).  Against the all-tunable engine on the same batch: same loss, bit-identical gradients for the
+    tensors that train, and after an optimizer step only those tensors have moved (image_newline belongs to the language-model group)."""
+    _need_gpu()
+    from radvlm_amd.engine import LlavaEngine
+    g, images = _toy_batch(golden_dir, "toy_anyres_e2e")
+    sizes = [tuple(s) for s in g["image_sizes"].tolist()]
+    names = set(parts.split(","))
+    meta = json.load(open(os.path.join(golden_dir, "toy_anyres_e2e_gradnorms.json")))
+    kw = dict(merge_type=meta["merge_type"], image_aspect_ratio=meta["aspect"], image_grid_pinpoints=meta["pinpoints"])
+    # the all-LM-parts-tunable engine with the SAME tower mode (a frozen tower applies fc1's activation in the GEMM epilogue: one rounding less)
+    full = LlavaEngine(GEOMETRIES["toy"], device="cuda:0", init="portable", seed=0, train_vision_tower="mm_vision_tower" in names, **kw)
+    eng = LlavaEngine(GEOMETRIES["toy"], device="cuda:0", init="portable", seed=0, train_vision_tower="mm_vision_tower" in names,
+                      freeze_lm="mm_language_model" not in names, freeze_projector="mm_mlp_adapter" not in names, **kw)
+    lf = float(full.forward(g["input_ids"], g["attention_mask"], g["labels"], images, image_sizes=sizes)); full.backward()
+    le = float(eng.forward(g["input_ids"], g["attention_mask"], g["labels"], images, image_sizes=sizes)); eng.backward()
+    assert lf == le
+
+    def part_of(n):
+        return "mm_vision_tower" if "vision_tower" in n else ("mm_mlp_adapter" if "mm_projector" in n else "mm_language_model")
+    trainable = [n for n in eng.lm.names() if n not in eng.frozen_names]
+    assert trainable and {part_of(n) for n in trainable} == names
+    assert all(part_of(n) in names for n in trainable) and "model.image_newline" in full.lm.offsets
+    for n in trainable:
+        assert torch.equal(eng.G(n), full.G(n)), n
+    before = {k: v.clone() for k, v in eng.state_dict().items()}
+    eng.optimizer_step(lr=1e-2, weight_decay=0.1, max_grad_norm=1.0)
+    torch.cuda.synchronize()
+    after = eng.state_dict()
+    moved = {k for k in before if not torch.equal(before[k], after[k])}
+    assert moved and {part_of(k) for k in moved} == names, sorted(moved)[:5]
+    # the clipped norm is the norm of the trainable gradients alone
+    want = torch.sqrt(sum(full.G(n).float().pow(2).sum() for n in trainable))
+    assert abs(float(eng.last_grad_norm) - float(want)) < 2e-3 * float(want)
+
+
+@pytest.mark.gpu
+def test_inputs_embeds_and_label_free_call_forms(golden_dir):
+    """LlavaLlamaForCausalLM.forward beyond the training call (llava_llama.py:69-120): `inputs_embeds` given -> no multimodal splice, fp32
+    logits (+ loss when labels are passed); `labels=None` with input_ids -> logits only.  Checked against the CPU oracle's decoder on the
+    same embeddings (same gates as the other toy end-to-end tests), and left- against right-padded masks (rotary positions are relative)."""
+    _need_gpu()
+    from oracle import llava_oracle as O
+    from radvlm_amd.llava.model import LlavaConfig, LlavaLlamaForCausalLM
+    geo = GEOMETRIES["toy"]
+    model = LlavaLlamaForCausalLM(LlavaConfig(geometry=geo), device="cuda:0", init="portable")
+    model.training = False
+    d, V = geo["lm"]["d"], geo["lm"]["vocab"]
+    gen = torch.Generator().manual_seed(3)
+    emb = (torch.randn(2, 40, d, generator=gen) * 0.05).to(torch.bfloat16)
+    mask = torch.ones(2, 40, dtype=torch.bool); mask[1, 29:] = False
+    labels = torch.randint(3, V, (2, 40), generator=gen); labels[:, :5] = -100
+    out = model(inputs_embeds=emb, attention_mask=mask, labels=labels)
+    P = {k: v.float().cpu() for k, v in model.engine.state_dict().items()}
+    ref = O.llama_forward(P, geo, emb.float(), torch.tensor([40, 29]))
+    ref_loss = float(O.causal_lm_loss(ref, torch.where(mask, labels, torch.full_like(labels, -100))))
+    lg = out.logits.cpu()
+    assert lg.dtype == torch.float32 and tuple(lg.shape) == (2, 40, V)
+    valid = mask[:, :, None].expand_as(lg)
+    assert float((lg - ref)[valid].abs().max() / ref[valid].abs().max()) < 1.5e-2
+    assert abs(float(out.loss) - ref_loss) < 5e-3
+    assert model(inputs_embeds=emb, attention_mask=mask).loss is None
+    with pytest.raises(ValueError, match="both"):
+        model(input_ids=torch.zeros(2, 40, dtype=torch.long), inputs_embeds=emb)
+    # left padding: the same 29 tokens at columns 11..39 give the same logits (positions are the column index, attention is relative)
+    lmask = torch.zeros(1, 40, dtype=torch.bool); lmask[0, 11:] = True
+    lemb = torch.zeros(1, 40, d, dtype=torch.bfloat16); lemb[0, 11:] = emb[1, :29]
+    left = model(inputs_embeds=lemb, attention_mask=lmask).logits.cpu()
+    assert float((left[0, 11:] - lg[1, :29]).abs().max() / lg[1, :29].abs().max()) < 3e-2
+    assert float(left[0, :11].abs().max()) == 0.0
+    # labels=None with input_ids: logits of the spliced sequence, no loss
+    g, images = _toy_batch(golden_dir)
+    o2 = model(input_ids=torch.from_numpy(g["input_ids"]), attention_mask=torch.from_numpy(g["attention_mask"]), images=images)
+    assert o2.loss is None and o2.logits is not None and o2.logits.dtype == torch.float32
+    want = torch.from_numpy(g["logits"]) if "logits" in g.files else None
+    if want is not None and want.shape == o2.logits.shape:
+        assert float((o2.logits.cpu() - want).abs().max() / want.abs().max()) < 1.5e-2

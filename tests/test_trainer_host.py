@@ -131,3 +131,34 @@ def test_missing_weights_and_remote_names_raise(tmp_path):
         load_pretrained(eng, lm_path=lm_dir)
     g, *_ = resolve_model_sources(ModelArguments(model_name_or_path=None, geometry="toy"))      # the explicit random-init switch
     assert g == geo
+
+
+def test_drop_last_false_completes_the_last_world_batch_from_the_epoch_head():
+    """--dataloader_drop_last (llava_trainer.py:348; finetune_radio_7b.sh:86 passes True): True drops the incomplete last world batch,
+    False completes it with the first samples of the same epoch's order (accelerate's even_batches sharding)."""
+    n, bs, world = 22, 4, 2
+    per_rank = {}
+    for drop in (True, False):
+        for rank in range(world):
+            it, steps = epoch_index_batches(n, None, 7, bs, world, rank, 1, drop_last=drop)
+            per_rank[(drop, rank)] = ([next(it) for _ in range(steps)], steps)
+    assert per_rank[(True, 0)][1] == 2 and per_rank[(False, 0)][1] == 3
+    order = torch.randperm(n, generator=torch.Generator().manual_seed(7)).tolist()
+    seen = [i for r in range(world) for b in per_rank[(False, r)][0] for i in b]
+    assert sorted(seen) == sorted(order + order[:2])                      # 22 samples + the 2 of the epoch's head that fill batch 3
+    assert per_rank[(False, 0)][0][:2] == per_rank[(True, 0)][0]          # the complete batches are the same either way
+
+
+def test_save_total_limit_keeps_the_newest_checkpoints(tmp_path):
+    """--save_total_limit N (HF Trainer._rotate_checkpoints; finetune_radio_7b.sh:72 passes 1)."""
+    from radvlm_amd.llava.train.llava_trainer import LLaVATrainer
+    for step in (5, 10, 100, 20):
+        os.makedirs(tmp_path / f"checkpoint-{step}")
+        (tmp_path / f"checkpoint-{step}" / "trainer_state.json").write_text("{}")
+    os.makedirs(tmp_path / "checkpoint-final")            # not a step directory: never touched
+    tr = LLaVATrainer(args=SimpleNamespace(save_total_limit=2))
+    assert tr._rotate_checkpoints(str(tmp_path), rank=1) == []              # only rank 0 deletes
+    assert sorted(tr._rotate_checkpoints(str(tmp_path), rank=0)) == ["checkpoint-10", "checkpoint-5"]
+    assert sorted(os.listdir(tmp_path)) == ["checkpoint-100", "checkpoint-20", "checkpoint-final"]
+    tr.args.save_total_limit = None
+    assert tr._rotate_checkpoints(str(tmp_path), rank=0) == []
