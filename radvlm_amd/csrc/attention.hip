@@ -12,6 +12,8 @@
 // accumulator registers (contraction order kappa(g,j) = 16*(2p + (j>>2)) + 4g + (j&3), matched by the A-side reads).
 //
 // Layouts: q,k,v,o,dq,dk,dv,dO are token-major rows [(b*S+s)*ld + h*HD + e]; lse/delta are fp32 [b,h,S_pad].
+// Compile-time switches that remain (measurement only): RV_ATTN_STAMPS (tools/attn_stamps.py), RV_DQ_NW=<4|8> waves of the dQ block,
+// RV_ATTN_ROW_MAX_EVERY_TILE (round 3's cross-lane row maximum on every tile: A side of profiles/r04_ab_attn_fwd_lane_local_max.txt).
 #include "attn_common.h"
 
 namespace {
@@ -374,32 +376,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
         // outgrown its stored maximum by more than 2^RESCALE_LAG (p then stays <= 2^RESCALE_LAG: nothing for fp32 sums or bf16 P).  After
         // the first tile that practically never happens, and the 64 accumulator multiplies + 2 exp per tile (a third of the tile's VALU
         // issue cycles; the loop was VALU-bound: 182 VALU for 64 MFMA per tile) leave the loop.
-#ifdef RV_ATTN_REAL_MAX        // A/B switch (measurement only): round 2's real-valued running maximum, rescaled every tile
-#pragma unroll
-        for (int qs = 0; qs < 2; ++qs) {
-            float mx = mxa[qs];
-            float sh = __shfl_xor(mx, 16, 64);
-            mx = max3_asm(mx, sh, sh);
-            sh = __shfl_xor(mx, 32, 64);
-            mx = max3_asm(mx, sh, sh);
-            const float ms = mx * sl2;
-            const float mnew = max3_asm(m[qs], ms, ms);
-            const float alpha = fexp2(m[qs] - mnew);
-            float rs = 0.f;
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float p = fexp2(__builtin_fmaf(s[qs][kb][r], sl2, -mnew));
-                    s[qs][kb][r] = p;
-                    rs += p;
-                }
-            l[qs] = l[qs] * alpha + rs;
-            m[qs] = mnew;
-#pragma unroll
-            for (int db = 0; db < DB; ++db) o[qs][db] *= alpha;
-        }
-#else
         constexpr float RESCALE_LAG = 8.f;
 #ifdef RV_ATTN_ROW_MAX_EVERY_TILE     // A/B switch (measurement only): round 3's cross-lane row maximum + candidate on every tile
         float cand[2];
@@ -462,7 +438,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
                 }
             l[qs] += rs;
         }
-#endif
 #ifdef RV_ATTN_STAMPS
         { asm volatile("" ::: "memory"); const long long a_ = __builtin_readcyclecounter();
           if (LATE) plV.stage(rsV, (t + 1) * vstep + hoff, nx + TILE, wid);

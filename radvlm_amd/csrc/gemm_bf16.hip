@@ -12,6 +12,10 @@
 // ds_read_b128 fragment reads are bank-conflict free, XCD-aware + grouped block->tile map.
 // Edge handling: out-of-range rows / k-chunks are sourced from a 16-byte zero page (per-lane source select),
 // so any M, N and any K % 8 == 0 work; stores are masked.
+// Compile-time switches that remain (measurement only; every other A/B variant of rounds 1-3 -- phase placement of the staging pieces,
+// priorities, non-persistent blocks, the uncompacted epilogue -- was measured, recorded under profiles/ and removed from the source):
+//   RV_GROUP_M=<n>  tile rows per group of the block -> tile map (tools/tile_order_probe.py; default 4)
+//   RV_STAMPS       diagnostic build with s_memtime stamps in the 256x256 kernel (tools/gemm_stamps.py)
 #include <type_traits>
 #include "common.h"
 #include "radvlm_hip.h"
@@ -474,14 +478,8 @@ DEVINL void fissue(Frag& f, const char* tile, unsigned base_rowmajor, int rowbas
 }
 
 #define BAR_LGKM() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-// Wave priority around the MFMA clusters.  Round 1's per-phase s_setprio 1 / 0 flips paid while a staging piece cost four address
-// instructions; with the buffer-addressed, branch-free K loop they COST 3.3 % (same-box A/B over the decoder's shapes: NT +3-4 %, NN
-// +7-8 %, TT +0-1.6 % without them; a static s_setprio 1 for waves 4-7, RV_STATIC_PRIO, is +2.9 %) -- default: no priority games.
-#ifdef RV_PHASE_PRIO
-#define RV_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define RV_PRIO(x) do { } while (0)
-#endif
+// No wave-priority instructions: per-phase s_setprio 1 / 0 flips around the MFMA clusters COST 3.3 % with the buffer-addressed, branch-free K
+// loop (same-box A/B over the decoder's shapes, round 2), a static s_setprio 1 for waves 4-7 cost 2.9 %; both switches are gone from the source.
 #ifdef RV_STAMPS
 // diagnostic build: cycles wave 0 spends parked at the mid-tile barrier [0], the end-of-tile vmcnt wait [1] and barrier [2]
 #define RV_ACC_BEGIN() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); dbg[3] = __builtin_readcyclecounter(); } while (0)
@@ -506,9 +504,6 @@ DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int br
     // ---- phase 1: read A(mh0), B(nh0) and, ahead of time, B(nh1).  Every read is issued from asm and retired by counted
     // waits: the k-step-0 MFMAs start as soon as THEIR six fragments are back, the k-step-1 MFMAs after the next six, and
     // the B(nh1) prefetch stays in flight behind both (hipcc's own bookkeeping waited for all 16 reads before the first MFMA).
-#ifdef RV_PH1_EARLY
-    ph1();
-#endif
     // issue order inside a k-step group: B0, A0, B1, A1, A2, A3 -- the first MFMA needs only the first two fragments
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -522,10 +517,7 @@ DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int br
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
         static_for<2>([&](auto j) { fissue<TB, true, 32 + decltype(j)::value * 16>(fb[1][decltype(j)::value][kk], Bt, bb[kk], brow0, kk, lane); });
-#ifndef RV_PH1_EARLY
     ph1();   // this phase's two staging pieces go out behind its 16 fragment reads (not in front: +0.8 % over the decoder shapes)
-#endif
-    RV_PRIO(1);
     // k-step 0 streams: each wait retires one more fragment (younger reads stay in flight) and releases the MFMAs it completes
     constexpr int R = G + B1_OPS;
 #define RV_C15(x) ((x) > 15 ? 15 : (x))
@@ -567,18 +559,12 @@ DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int br
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(b[0][j][1], a[i][1], acc[i][j]);
-    RV_PRIO(0);
 
     // ---- phase 2: B(nh1) has landed behind phase 1's MFMAs; A(mh1) is read k-step by k-step behind this phase's MFMAs
-#ifndef RV_PH2_LATE
     ph2();
-#endif
     RV_ACC_BEGIN();
     BAR_LGKM();   // every wave's B reads of tile t are complete -> the B slot of tile t may be restaged
     RV_ACC_END(0);
-#ifdef RV_PH2_LATE
-    ph2();
-#endif
     fwait4<TB, 0>(fb[1][0][0], fb[1][1][0], fb[1][0][1], fb[1][1][1]);   // already retired by the barrier's wait: pins the consumers below it
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -587,56 +573,40 @@ DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int br
         for (int j = 0; j < 2; ++j) b[1][j][kk] = frag_get<TB>(fb[1][j][kk]);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-        RV_PRIO(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma16(b[1][j][kk], a[i][kk], acc[i][2 + j]);
-        RV_PRIO(0);
         // a[.][kk] is dead now: fetch A(mh1) for this k-step while the other k-step's MFMAs run
         static_for<4>([&](auto i) { fissue<TA, false, 64 + decltype(i)::value * 16>(fa[decltype(i)::value][kk], At, ab[kk], 0, kk, lane); });
     }
 
     // ---- phase 3
-#ifndef RV_PH3_MID
     ph3();
-#endif
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         if (kk == 0) fwait4<TA, 4 * OA>(fa[0][0], fa[1][0], fa[2][0], fa[3][0]);   // the k-step-1 reads stay in flight
         else {
-#ifdef RV_PH3_MID
-            ph3();
-#endif
             fwait4<TA, 0>(fa[0][1], fa[1][1], fa[2][1], fa[3][1]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i][kk] = frag_get<TA>(fa[i][kk]);
-        RV_PRIO(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[4 + i][2 + j] = mfma16(b[1][j][kk], a[i][kk], acc[4 + i][2 + j]);
-        RV_PRIO(0);
     }
 
     // ---- phase 4
-#ifndef RV_PH4_MID
     ph4();
-#endif
-    RV_PRIO(1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-#ifdef RV_PH4_MID
-        if (kk == 1) { __builtin_amdgcn_sched_barrier(0); ph4(); __builtin_amdgcn_sched_barrier(0); }
-#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[4 + i][j] = mfma16(b[0][j][kk], a[i][kk], acc[4 + i][j]);
     }
-    RV_PRIO(0);
 }
 
 template <int MODE>
@@ -645,7 +615,6 @@ DEVINL void epilogue_256(const f32x4 (&acc)[8][4], const GemmParams& P, int m0, 
     // n = n0 + wc*64 + 32a + 8*(lane>>4) + {0..7}: acc[i][2a][0..3] then acc[i][2a+1][0..3]
     const bool n_vec_ok = (P.N % 8 == 0) && (P.ldc % 8 == 0) && (!P.R || P.ldr % 8 == 0) &&
                           ((((uintptr_t)P.C) | ((uintptr_t)P.R) | ((uintptr_t)P.bias)) & 15) == 0;
-#ifndef RV_NO_COMPACT_EPILOGUE
     // the common case (plain bf16 product: every dgrad / wgrad-free forward GEMM of the decoder) gets a compact instruction stream:
     // the general path below is ~20k instructions of mostly untaken branches per kernel, fetched once per tile
     if (MODE == 0 && !P.bias && P.act == RV_ACT_NONE && !P.R && !P.out_f32 && P.alpha == 1.f && n_vec_ok && !P.drop_thr) {
@@ -660,7 +629,6 @@ DEVINL void epilogue_256(const f32x4 (&acc)[8][4], const GemmParams& P, int m0, 
         });
         return;
     }
-#endif
     static_for<16>([&](auto ia) {
         constexpr int i = decltype(ia)::value >> 1, a = decltype(ia)::value & 1;
         const int m = m0 + wr * 128 + i * 16 + (lane & 15);
@@ -879,11 +847,7 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
     // PERSIST (plain whole-tile launches with buffer-addressed staging): a block walks the tiles blockIdx.x, + gridDim.x, ... (grid =
     // min(tiles, CUs); same tile order per XCD as the one-tile-per-block launch) and issues the first K-tile of its NEXT output tile
     // before the epilogue of the current one, so the fill of the staging pipeline and the launch gap hide behind the epilogue's stores.
-#ifdef RV_NO_PERSIST
-    constexpr bool PERSIST = false;
-#else
     constexpr bool PERSIST = (MODE == 0 || MODE == 1 || MODE == 3) && BUF;
-#endif
     int vtile = blockIdx.x, kslice = 0;
     bool sliced = MODE == 2;
     if (MODE == 2) { vtile = (int)blockIdx.x / P.splits; kslice = (int)blockIdx.x % P.splits; }
@@ -991,9 +955,6 @@ __global__ __launch_bounds__(512, 1) void gemm_kernel_256(GemmParams P) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#ifdef RV_STATIC_PRIO
-    if (wid >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
     int aslot = 0;          // A ring slot of tile t (t % 3)
     long long dbg[4] = {0, 0, 0, 0};   // diagnostic build only (RV_STAMPS): parked-cycle accumulators; dead code otherwise
     // One K-tile step.  STAGE = this step issues the staging of tile t + 2 (all steps but the last two): the steady-state loop is
@@ -1232,11 +1193,9 @@ static void launch256m(const GemmParams& P, hipStream_t st) {
     int grid = blocks;
     GemmParams Q = P;
     Q.pgrid = MODE == 3 ? P.n_full : blocks;
-#ifndef RV_NO_PERSIST
     // persistent form: one block per CU walks the whole tiles (MODE 3: + the K-slice blocks of the tail tiles behind them)
     if (g_persist && BUF && (MODE == 0 || MODE == 1) && blocks > cu_budget()) { grid = cu_budget(); Q.pgrid = grid; }
     if (g_persist && BUF && MODE == 3 && P.n_full > cu_budget()) { Q.pgrid = cu_budget(); grid = Q.pgrid + (nwg - P.n_full) * P.splits; }
-#endif
     hipLaunchKernelGGL((gemm_kernel_256<TA, TB, MODE, EPI_NONE, BUF>), dim3(grid), dim3(512), LDS_BYTES2, st, Q);
     if (MODE == 3) hipLaunchKernelGGL(tail_reduce_kernel, dim3((nwg - P.n_full) * 32), dim3(256), 0, st, P);
     if (MODE == 2) {
@@ -1367,9 +1326,7 @@ static void launch_fused1(const GemmParams& P, hipStream_t st) {
     static bool attr = false;      // once per instantiation (see the launch-configuration note above)
     if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_kernel_256<false, TB, 0, EPI, BUF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES2); attr = true; }
     int grid = P.tiles_m * P.tiles_n;
-#ifndef RV_NO_PERSIST
     if (g_persist && BUF && grid > cu_budget()) grid = cu_budget();
-#endif
     hipLaunchKernelGGL((gemm_kernel_256<false, TB, 0, EPI, BUF>), dim3(grid), dim3(512), LDS_BYTES2, st, P);
 }
 template <int EPI, bool TB>

@@ -52,7 +52,17 @@ def _no_decay(name, shape):
     return len(shape) == 1 and ("norm" in name or name.endswith("bias"))
 
 
-def test_config2_full_size_forward_backward_two_adamw_steps():
+def _planned_layers():
+    """What the test will run, decided at collection so that the test id says it (`...[32_layers]`): the full depth, or the explicit
+    RV_FULLSIZE_LAYERS override.  A host that cannot hold the fp32 oracle of the full model (< 180 GB free) FAILS the full-depth test
+    instead of silently shrinking it -- run it knowingly reduced with RV_FULLSIZE_LAYERS=8."""
+    want = os.environ.get("RV_FULLSIZE_LAYERS")
+    gname = os.environ.get("RV_FULLSIZE_GEOMETRY", "llava15_7b")
+    return int(want) if want else GEOMETRIES[gname]["lm"]["layers"]
+
+
+@pytest.mark.parametrize("layers", [pytest.param(_planned_layers(), id=f"{_planned_layers()}_layers")])
+def test_config2_full_size_forward_backward_two_adamw_steps(layers):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from oracle import bf16_emulation as E
@@ -66,7 +76,9 @@ def test_config2_full_size_forward_backward_two_adamw_steps():
     # 2.5 minutes), its record is profiles/r03_full_size_parity_qwen2_siglip.json
     gname = os.environ.get("RV_FULLSIZE_GEOMETRY", "llava15_7b")
     full_layers = GEOMETRIES[gname]["lm"]["layers"]
-    layers = int(want) if want else (full_layers if _avail_gb() >= 180 else 8)
+    if not want and _avail_gb() < 180:
+        pytest.fail(f"{_avail_gb():.0f} GB of host memory available: the fp32 oracle of all {full_layers} layers needs ~180 GB.  Set "
+                    "RV_FULLSIZE_LAYERS=8 to run the reduced model knowingly (the test id then reads [8_layers]).")
     geo = copy.deepcopy(GEOMETRIES[gname])
     geo["lm"]["layers"] = layers
     V = geo["lm"]["vocab"]
