@@ -398,20 +398,29 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 // names every destination, so no consumer is scheduled above it) -- guide section 5.7 form (ii).
 struct Frag { bf16x8 n; s16x4 t0, t1; };
 
-template <bool T, bool PERM = false>
-DEVINL void frag_issue(Frag& f, const char* tile, int fbase, int kk, int lane) {
-    if (!T) { f.n = read_frag(tile, fbase + (lane & 15), kk * 4 + (lane >> 4)); return; }
+// Transposed (contraction-major) operand fragment: two ds_read_b64_tr_b16 whose addresses are ONE per-lane base + immediates.  The base
+// covers everything that depends on the lane, the tile's stage and the 32-feature group (the XOR swizzle mixes the group's chunk bits with
+// the lane's row bits: not an additive constant); the k-step (+32 rows = 8192 bytes: tswz sees the same (m & 3) and ((m >> 3) & 1)), the
+// second read's rows + 4 (1024 bytes, same swizzle term) and -- PERM -- the 16-feature tile inside its 32-feature group (8 bytes) are
+// immediates of the read.  (Round 3 passed every address in a register: 41 v_add_u32 + 8 v_add3_u32 per K-tile and wave next to 48 reads
+// and 64 MFMAs -- the weight-gradient forms were instruction-ISSUE bound, 2 x 1160 issue cycles per SIMD against 2048 MFMA cycles.)
+// rowbase must be a multiple of 32 (0 for A, the wave's 64-column half for B).
+template <bool PERM, int FOFF>
+DEVINL unsigned tfrag_base(const char* tile, int rowbase, int lane) {
     const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int fb = rowbase + (PERM ? (FOFF & ~31) : FOFF);
     // the lane supplies the address of 4 consecutive features: fbase + 4p, or (PERM) 32a + 8p + 4j for tile j of group a
-    const int c16 = PERM ? ((fbase & ~31) >> 3) + p : (fbase >> 3) + (p >> 1);
-    const int half = PERM ? ((fbase >> 4) & 1) : (p & 1);
-    const int m0 = kk * 32 + 8 * g + q, m1 = m0 + 4;
-    const char* a0 = tile + m0 * 256 + ((c16 ^ tswz(m0)) << 4) + (half << 3);
-    const char* a1 = tile + m1 * 256 + ((c16 ^ tswz(m1)) << 4) + (half << 3);
-    const unsigned o0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)a0;
-    const unsigned o1 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)a1;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.t0) : "v"(o0) : "memory");
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.t1) : "v"(o1) : "memory");
+    const int c16 = PERM ? (fb >> 3) + p : (fb >> 3) + (p >> 1);
+    const int half = PERM ? 0 : (p & 1);
+    const int m = 8 * g + q;
+    const char* a = tile + m * 256 + ((c16 ^ tswz(m)) << 4) + (half << 3);
+    return (unsigned)(unsigned long)(__attribute__((address_space(3))) const char*)a;
+}
+template <bool PERM, int FOFF, int KK>
+DEVINL void frag_issue_t(Frag& f, unsigned base) {
+    constexpr int IMM = KK * 8192 + (PERM ? ((FOFF >> 4) & 1) * 8 : 0);
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.t0) : "v"(base), "i"(IMM) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.t1) : "v"(base), "i"(IMM + 1024) : "memory");
 }
 // LEFT = number of younger LDS operations that may stay in flight (LDS ops retire in order; compiler-issued reads in
 // between only make the wait stricter, never weaker).
@@ -471,9 +480,9 @@ DEVINL void fwait4(Frag& a, Frag& b, Frag& c, Frag& d) {
 }
 // One fragment read, either operand form: FOFF = feature-row offset (compile time) from `rowbase`; row-major operands use the
 // per-k-step base address + an immediate, transposed ones the tr-read pair of frag_issue.
-template <bool T, bool PERM, int FOFF>
-DEVINL void fissue(Frag& f, const char* tile, unsigned base_rowmajor, int rowbase, int kk, int lane) {
-    if constexpr (T) frag_issue<true, PERM>(f, tile, rowbase + FOFF, kk, lane);
+template <bool T, bool PERM, int FOFF, int KK>
+DEVINL void fissue(Frag& f, const char* tile, unsigned base_rowmajor, int rowbase, int lane) {
+    if constexpr (T) frag_issue_t<PERM, FOFF, KK>(f, tfrag_base<PERM, FOFF>(tile, rowbase, lane));
     else frag_issue_imm<FOFF * 128>(f, base_rowmajor);
 }
 
@@ -505,18 +514,19 @@ DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int br
     // waits: the k-step-0 MFMAs start as soon as THEIR six fragments are back, the k-step-1 MFMAs after the next six, and
     // the B(nh1) prefetch stays in flight behind both (hipcc's own bookkeeping waited for all 16 reads before the first MFMA).
     // issue order inside a k-step group: B0, A0, B1, A1, A2, A3 -- the first MFMA needs only the first two fragments
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        fissue<TB, true, 0>(fb[0][0][kk], Bt, bb[kk], brow0, kk, lane);
-        fissue<TA, false, 0>(fa[0][kk], At, ab[kk], 0, kk, lane);
-        fissue<TB, true, 16>(fb[0][1][kk], Bt, bb[kk], brow0, kk, lane);
-        fissue<TA, false, 16>(fa[1][kk], At, ab[kk], 0, kk, lane);
-        fissue<TA, false, 32>(fa[2][kk], At, ab[kk], 0, kk, lane);
-        fissue<TA, false, 48>(fa[3][kk], At, ab[kk], 0, kk, lane);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-        static_for<2>([&](auto j) { fissue<TB, true, 32 + decltype(j)::value * 16>(fb[1][decltype(j)::value][kk], Bt, bb[kk], brow0, kk, lane); });
+    static_for<2>([&](auto kt) {
+        constexpr int kk = decltype(kt)::value;
+        fissue<TB, true, 0, kk>(fb[0][0][kk], Bt, bb[kk], brow0, lane);
+        fissue<TA, false, 0, kk>(fa[0][kk], At, ab[kk], 0, lane);
+        fissue<TB, true, 16, kk>(fb[0][1][kk], Bt, bb[kk], brow0, lane);
+        fissue<TA, false, 16, kk>(fa[1][kk], At, ab[kk], 0, lane);
+        fissue<TA, false, 32, kk>(fa[2][kk], At, ab[kk], 0, lane);
+        fissue<TA, false, 48, kk>(fa[3][kk], At, ab[kk], 0, lane);
+    });
+    static_for<2>([&](auto kt) {
+        constexpr int kk = decltype(kt)::value;
+        static_for<2>([&](auto j) { fissue<TB, true, 32 + decltype(j)::value * 16, kk>(fb[1][decltype(j)::value][kk], Bt, bb[kk], brow0, lane); });
+    });
     ph1();   // this phase's two staging pieces go out behind its 16 fragment reads (not in front: +0.8 % over the decoder shapes)
     // k-step 0 streams: each wait retires one more fragment (younger reads stay in flight) and releases the MFMAs it completes
     constexpr int R = G + B1_OPS;
@@ -571,15 +581,15 @@ DEVINL void ktile_256(f32x4 (&acc)[8][4], const char* At, const char* Bt, int br
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int j = 0; j < 2; ++j) b[1][j][kk] = frag_get<TB>(fb[1][j][kk]);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    static_for<2>([&](auto kt) {
+        constexpr int kk = decltype(kt)::value;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[i][2 + j] = mfma16(b[1][j][kk], a[i][kk], acc[i][2 + j]);
         // a[.][kk] is dead now: fetch A(mh1) for this k-step while the other k-step's MFMAs run
-        static_for<4>([&](auto i) { fissue<TA, false, 64 + decltype(i)::value * 16>(fa[decltype(i)::value][kk], At, ab[kk], 0, kk, lane); });
-    }
+        static_for<4>([&](auto i) { fissue<TA, false, 64 + decltype(i)::value * 16, kk>(fa[decltype(i)::value][kk], At, ab[kk], 0, lane); });
+    });
 
     // ---- phase 3
     ph3();

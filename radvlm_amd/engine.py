@@ -542,9 +542,9 @@ class LlavaEngine:
         """bf16 bytes one decoder layer keeps per token row for backward: x, h1, q|k|v, attn, x_mid, h2, gate|up, act (+ fp32 statistics)."""
         d, F = self.l["d"], self.l["ffn"]
         n = 2 * (6 * d + 2 * self.kvd + 3 * F) + 4 * (2 + self.l["heads"])
-        if self.lora:                       # the seven adapted modules keep their r-wide down-projections
+        if getattr(self, "lora", None):     # the seven adapted modules keep their r-wide down-projections
             n += 2 * 7 * self.lora["r"]
-        if self.hd != 128:                  # head_dim 64 kernels read a V^T copy
+        if getattr(self, "hd", 128) != 128:  # head_dim 64 kernels read a V^T copy
             n += 2 * self.kvd
         return n
 

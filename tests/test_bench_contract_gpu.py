@@ -52,6 +52,9 @@ def test_self_spawned_two_rank_line():
     d = _run(["--gpus", "2"], env={"RV_BENCH_REHEARSAL": "1"})
     _check(d, 2)
     assert "gloo" in d["distributed"]["backend"] and d["distributed"]["exposed_comm_ms_per_step"] >= 0.0
+    # one driver run at N > 1 tells exposed communication, straggler spread over ranks and how many collectives a step issues
+    dd = d["distributed"]
+    assert 0.0 < dd["ms_per_step_min"] <= dd["ms_per_step_max"] <= d["ms_per_step"] * 1.001 and dd["bucket_count"] >= 2
 
 
 def test_rccl_branch_runs_in_a_one_rank_group():

@@ -47,6 +47,20 @@ w = eng.lm.flat.float()
 ws = [torch.zeros_like(w) for _ in range(world)]
 dist.all_gather(ws, w)
 assert torch.equal(ws[0], ws[1])   # replicas stay bit-identical
+# replica consistency machinery (train() runs it after init / load / resume and at every save step): identical replicas pass; a rank whose
+# copy drifted is reported by EVERY rank, by buffer name; the wrap-time broadcast from rank 0 (what DDP does in the reference) repairs it
+eng.check_replicas("after one step")
+if rank == 1:
+    eng.lm.flat[123] += 0.5
+    eng.m[7] += 1e-3
+try:
+    eng.check_replicas("after a faulty step")
+    raise SystemExit("divergence not detected")
+except RuntimeError as e:
+    assert "'parameters'" in str(e) and "'exp_avg'" in str(e) and "'exp_avg_sq'" not in str(e) and "'fp32_master'" not in str(e), str(e)
+eng.broadcast_parameters()
+eng.check_replicas("after the broadcast")
+eng.barrier()
 dist.destroy_process_group()
 print("OK", rank, rel)
 """

@@ -356,6 +356,10 @@ def test_reference_api_surface_and_trainer(golden_dir, tmp_path):
         bos_token_id, pad_token_id, model_max_length, legacy, padding_side = 1, 0, 256, True, "right"
 
         def __call__(self, s, **kw):
+            if isinstance(s, (list, tuple)):      # text-only samples: the batched call form (return_tensors="pt", padding="longest")
+                rows = [self(t).input_ids for t in s]
+                width = max(len(r) for r in rows)
+                return Ids(torch.tensor([r + [self.pad_token_id] * (width - len(r)) for r in rows], dtype=torch.long))
             ids = [1]
             for k, piece in enumerate(s.split("</s>")):
                 if k:

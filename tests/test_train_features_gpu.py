@@ -338,6 +338,14 @@ def test_auto_recompute_keeps_activations_when_they_fit(golden_dir):
     free, _ = torch.cuda.mem_get_info()
     rows_too_many = int(free // eng.activation_bytes_per_row())       # one layer alone would fill the device
     assert eng._recompute_layers(rows_too_many) == eng.l["layers"]
+    assert eng._recompute_layers(96) == 0 and eng._recompute_cache[96] == 0          # one decision per row count
+    # HF's gradient_checkpointing_enable() selects the same policy (it used to force every layer: + 1/3 forward cost for nothing)
+    from radvlm_amd.llava.model import LlavaConfig, LlavaLlamaForCausalLM
+    m = LlavaLlamaForCausalLM(LlavaConfig(geometry=GEOMETRIES["toy"]), device="cuda:0", init="fast")
+    m.gradient_checkpointing_enable()
+    assert m.engine.recompute == "auto" and m.is_gradient_checkpointing
+    m.gradient_checkpointing_disable()
+    assert m.engine.recompute is False
     # 7B widths: 32 pairs x 704 tokens keep ~95 GB of activations
     big = LlavaEngine.__new__(LlavaEngine)
     big.l, big.kvd = GEOMETRIES["llava15_7b"]["lm"], 4096
