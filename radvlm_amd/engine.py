@@ -39,6 +39,8 @@ class LlavaEngine:
         self.geo = geo
         assert recompute in (False, True, "auto")
         self.recompute = recompute            # activation recompute policy of the decoder layers (_recompute_layers)
+        self.head_rows = "labeled"            # final norm + lm_head + cross entropy on the rows that carry a label ("all": every row)
+        self.last_layer_rows = "labeled"      # ... and the last decoder layer's o_proj / norm / MLP (needs head_rows == "labeled")
         self._recompute_cache, self._recompute_forced = {}, False
         # packed (varlen) decoder batches: True / False / "auto" (pack when the samples of a batch differ in length): the decoder
         # then runs on sum(len_b) token rows instead of B * max(len_b) -- no padding rows through GEMMs, norms, CE
@@ -152,15 +154,7 @@ class LlavaEngine:
         # force_grad_sync: a one-rank group still issues every bucket's collective (single-GPU rehearsal of the RCCL path)
         self.force_grad_sync = bool(force_grad_sync) and process_group is not None
         self.sync = FlatGradSync(self.grads, process_group, force=self.force_grad_sync) if (self.world > 1 or self.force_grad_sync) else None
-        if self.sync is not None and self.device.type == "cuda":
-            # the all-reduce kernels share the CUs with backward's GEMMs: one-tile-per-block launches lose part of a round to them, a
-            # persistent block that cannot start would delay its whole share of the tiles (rv_gemm_select_kernel, include/radvlm_hip.h)
-            from . import lib
-            lib.load().rv_gemm_select_kernel(40)
-        elif self.device.type == "cuda":
-            # the switch is process-wide: an engine without gradient collectives created after one with them gets the persistent blocks back
-            from . import lib
-            lib.load().rv_gemm_select_kernel(41)
+        self._select_gemm_launch_shape()
         self.ctx = None
         self.grad_accum_started = False
         self.loss_scale = 1.0
@@ -169,6 +163,15 @@ class LlavaEngine:
         self.fused = os.environ.get("RV_FUSED", "1") != "0"
         assert padding_side in ("right", "left")
         self.padding_side = padding_side     # config.tokenizer_padding_side (llava_arch.py:520-524)
+
+    def _select_gemm_launch_shape(self):
+        """The all-reduce kernels of a data-parallel run share the CUs with backward's GEMMs: one-tile-per-block launches lose part of a
+        round to them, a persistent block that cannot start would delay its whole share of the tiles (rv_gemm_select_kernel 40 / 41,
+        include/radvlm_hip.h).  The switch is process-wide, so it is set at the top of every forward / backward of THIS engine: a second
+        engine in the process (an eval or reference model with or without gradient collectives) cannot leave the wrong shape behind."""
+        if self.device.type == "cuda":
+            from . import lib
+            lib.load().rv_gemm_select_kernel(40 if self.sync is not None else 41)
 
     # ------------------------------------------------------------------ vocabulary
     def resize_token_embeddings(self, new_vocab):
@@ -572,8 +575,11 @@ class LlavaEngine:
         self._recompute_cache[M] = max(0, L - keep)     # one decision per row count: later steps see less free memory only because of this one's caches
         return self._recompute_cache[M]
 
-    def _layer_forward(self, i, x, g):
-        """One decoder layer (modeling_llama.py:852-911) on token rows x -> (x_out, the activations backward needs)."""
+    def _layer_forward(self, i, x, g, rows=None):
+        """One decoder layer (modeling_llama.py:852-911) on token rows x -> (x_out, the activations backward needs).
+        rows (LAST layer only; int32 device index, -1 = zero pad row): the rows whose output anything downstream reads -- the labelled rows
+        (forward()).  Attention still runs on every row (all rows are keys / values), but o_proj, the residual, the second norm and the
+        MLP are evaluated on the gathered rows alone: x_out and the saved x_mid, rstd2, h2, gu, act then have rows.numel() rows."""
         d, F, H = self.l["d"], self.l["ffn"], self.l["heads"]
         hd, Hkv, kvd = self.hd, self.Hkv, self.kvd
         B, S, s_pad, lens, cu, pos, cs = g["B"], g["S"], g["s_pad"], g["lens"], g["cu"], g["pos"], g["cs"]
@@ -594,7 +600,14 @@ class LlavaEngine:
         else:
             vT = ops.transpose_heads(qkv[:, d + kvd:], B, S, Hkv, hd, s_pad, cu=cu)
             attn, lse = ops.attn_fwd(qkv[:, :d], qkv[:, d:d + kvd], vT, B, S, H, hd, s_pad, causal=True, lens=lens, kv_heads=Hkv, cu=cu)
-        if self.lora:
+        attn_sel = None
+        if rows is not None:
+            attn_sel = ops.gather_rows(rows, d, attn)
+            if self.lora:
+                x_mid = self._lora_linear(attn_sel, lv["o"], i, (("self_attn.o_proj", 0, d),), sv, residual=ops.gather_rows(rows, d, x))
+            else:
+                x_mid = ops.gemm_nt(attn_sel, lv["o"], residual=ops.gather_rows(rows, d, x))
+        elif self.lora:
             x_mid = self._lora_linear(attn, lv["o"], i, (("self_attn.o_proj", 0, d),), sv, residual=x)
         else:
             x_mid = ops.gemm_nt(attn, lv["o"], residual=x)
@@ -611,7 +624,10 @@ class LlavaEngine:
             x_out = self._lora_linear(act, lv["down"], i, (("mlp.down_proj", 0, d),), sv, residual=x_mid)
         else:
             x_out = ops.gemm_nt(act, lv["down"], residual=x_mid)
-        return x_out, dict(x=x, rstd1=rstd1, h1=h1, qkv=qkv, attn=attn, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2, gu=gu, act=act, lora=sv)
+        acts = dict(x=x, rstd1=rstd1, h1=h1, qkv=qkv, attn=attn, lse=lse, x_mid=x_mid, rstd2=rstd2, h2=h2, gu=gu, act=act, lora=sv)
+        if attn_sel is not None:
+            acts["attn_sel"] = attn_sel
+        return x_out, acts
 
     def forward(self, input_ids, attention_mask, labels, images, image_sizes=None, want_logits=False, loss_scale=None):
         """One training forward. Returns loss (fp32 device tensor [1], never scaled); keeps the context for backward().
@@ -621,6 +637,7 @@ class LlavaEngine:
         l = self.l
         d, F, H, V, L = l["d"], l["ffn"], l["heads"], l["vocab"], l["layers"]
         hd, Hkv, kvd = self.hd, self.Hkv, self.kvd
+        self._select_gemm_launch_shape()
         plan = self.plan(input_ids, attention_mask, labels, images, image_sizes)
         self.lora_step += 1
         pix = torch.cat([(im if im.ndim == 4 else im[None]) for im in images], 0)
@@ -674,14 +691,6 @@ class LlavaEngine:
         # activation recompute (the reference's --gradient_checkpointing, train/train.py:164,1505-1513): layers [0, n_re) keep only their
         # input and re-run their forward inside backward (bit-identical: the kernels are deterministic, LoRA dropout masks regenerable)
         n_re = self._recompute_layers(M)
-        layers = []
-        for i in range(L):
-            x_out, acts = self._layer_forward(i, x, geom)
-            layers.append(dict(x=x, lora={}) if i < n_re else acts)
-            x = x_out
-        ctx["geom"], ctx["n_recomputed"] = geom, n_re
-        hN, rstdN = ops.rmsnorm_fwd(x, self.W("model.norm.weight"), self.eps)
-        logits = ops.gemm_nt(hN, self.W("lm_head.weight"))
         tgt = shifted_labels(plan["labels"])
         if tgt.size and int(tgt.max()) >= self.vocab:     # torch's cross_entropy raises on an out-of-range target too
             raise IndexError(f"label {int(tgt.max())} is out of range for a vocabulary of {self.vocab}")
@@ -690,12 +699,46 @@ class LlavaEngine:
         tgt = tgt.reshape(-1)
         if packed:
             tgt = tgt[valid_idx]
+        # The loss reads the logits of the rows that carry a label and of no other row (modeling_llama.py:1326-1337: ignore_index rows
+        # contribute neither to the loss nor -- their dlogits being exactly zero -- to any gradient), and nothing after the last decoder
+        # layer mixes rows.  So the final norm, the lm_head product, the cross entropy and their backward run on the LABELLED rows only
+        # (an instruction sample labels its answer tokens: 64 of 704 rows in the BASELINE workload, 9 % of a 3 x 5.9 TFLOP head).  Same
+        # loss, same gradients (the dropped terms are exact zeros); HF's `logits_to_keep` is the same idea.  head_rows = "all" restores
+        # the full product (A/B, tests); callers that want logits get the full fp32 product either way.
+        head_idx = None
+        lab_rows = np.nonzero(tgt != -100)[0]
+        if self.head_rows == "labeled" and 0 < lab_rows.size <= 0.75 * M:
+            n_sel = _ru(int(lab_rows.size), 64)           # whole 64-row groups: the weight gradient contracts over these rows
+            head_idx = np.full(n_sel, -1, dtype=np.int32)
+            head_idx[:lab_rows.size] = lab_rows
+            t_sel = np.full(n_sel, -100, dtype=tgt.dtype)
+            t_sel[:lab_rows.size] = tgt[lab_rows]
+            tgt = t_sel
+        # The same holds one step earlier: a row of the LAST decoder layer's output feeds its own logits row and nothing else, so that layer's
+        # o_proj, second norm and MLP (304 MFLOP per row at 7B widths, x 3 with backward) are dead for the unlabelled rows as well; its
+        # attention still runs on every row.  Not taken when the caller wants every row's logits.  (LoRA: the adapters' dropout masks are
+        # indexed by the element position in the gathered tensor -- another mask than the all-rows run draws, regenerated identically in
+        # backward.)
+        last_sel = head_idx is not None and self.last_layer_rows == "labeled" and not want_logits
+        layers = []
+        for i in range(L):
+            x_out, acts = self._layer_forward(i, x, geom, rows=self._dev(head_idx) if (last_sel and i == L - 1) else None)
+            layers.append(dict(x=x, lora={}) if i < n_re else acts)
+            x = x_out
+        ctx["geom"], ctx["n_recomputed"] = geom, n_re
+        if head_idx is None or last_sel:
+            x_head = x
+        else:
+            x_head = ops.gather_rows(self._dev(head_idx), d, x)          # pad rows are zero and carry no label
+        hN, rstdN = ops.rmsnorm_fwd(x_head, self.W("model.norm.weight"), self.eps)
+        logits = ops.gemm_nt(hN, self.W("lm_head.weight"))
         tgt_t = self._dev(tgt)
         logits_out = None
         if want_logits:
             # callers get the reference's fp32 [B, S, V] (llava_llama.py:69-120 -> logits.float()): the lm_head GEMM once more with
             # fp32 output, i.e. the accumulators without the bf16 store the training path's loss reads (eval / tests only)
-            lf = ops.gemm_nt(hN, self.W("lm_head.weight"), out_dtype=torch.float32)
+            hN_all = hN if head_idx is None else ops.rmsnorm_fwd(x, self.W("model.norm.weight"), self.eps)[0]
+            lf = ops.gemm_nt(hN_all, self.W("lm_head.weight"), out_dtype=torch.float32)
             if packed:          # padded shape, padding rows zero
                 logits_out = torch.zeros(B * S, V, dtype=torch.float32, device=dev)
                 logits_out[self._dev(valid_idx)] = lf
@@ -705,8 +748,8 @@ class LlavaEngine:
         # CE writes dlogits (scaled by loss_scale/count/world) over the logits buffer
         gscale = (self.loss_scale if loss_scale is None else loss_scale) / self.world
         loss, _ = self._cross_entropy(logits, tgt_t, self.vocab, inv, gscale)   # V = table rows (pad rows included), CE sees the logical vocabulary
-        ctx.update(B=B, S=S, M=M, s_pad=s_pad, lens=lens, cu=cu, pos=pos, layers=layers, x_last=x, rstdN=rstdN, hN=hN, dlogits=logits,
-                   table_rows=table.shape[0], count=count)
+        ctx.update(B=B, S=S, M=M, s_pad=s_pad, lens=lens, cu=cu, pos=pos, layers=layers, x_last=x_head, rstdN=rstdN, hN=hN, dlogits=logits,
+                   table_rows=table.shape[0], count=count, head_idx=head_idx, head_rows=int(lab_rows.size), last_sel=last_sel)
         self.ctx = ctx
         self.last_logits = logits_out
         return loss
@@ -858,6 +901,7 @@ class LlavaEngine:
         """Backward of the last forward(); gradients land in self.grads (bf16, flat)."""
         c = self.ctx
         assert c is not None, "forward() first"
+        self._select_gemm_launch_shape()
         l = self.l
         d, F, H, V, L = l["d"], l["ffn"], l["heads"], l["vocab"], l["layers"]
         hd, Hkv, kvd = self.hd, self.Hkv, self.kvd
@@ -869,13 +913,20 @@ class LlavaEngine:
         dhN = self._linear_bwd(c["dlogits"], c["hN"], self.W("lm_head.weight"), None if frozen_lm else self.G("lm_head.weight"))
         dx, _ = ops.rmsnorm_bwd(dhN, c["x_last"], self.W("model.norm.weight"), c["rstdN"],
                                 dw=None if frozen_lm else self.G("model.norm.weight"), dw_accumulate=acc)
+        back = None
+        if c["head_idx"] is not None:       # the head ran on the labelled rows: every other row of the last layer's output has zero gradient
+            back = np.full(M, -1, dtype=np.int32)
+            back[c["head_idx"][:c["head_rows"]]] = np.arange(c["head_rows"], dtype=np.int32)
+            back = self._dev(back)
+            if not c["last_sel"]:
+                dx = ops.gather_rows(back, d, dx)
         if not frozen_lm:
             self._bucket_done("lm_head.weight", "lm_head.weight")
             self._bucket_done("model.norm.weight", "model.norm.weight")
         for i in reversed(range(L)):
             a = c["layers"][i]
             if "h1" not in a:      # activation recompute: this layer kept only its input
-                _, a = self._layer_forward(i, a["x"], c["geom"])
+                _, a = self._layer_forward(i, a["x"], c["geom"], rows=self._dev(c["head_idx"]) if (c["last_sel"] and i == L - 1) else None)
             lv, gv = self._layer_views(i), self._layer_views(i, self.grads)
             sv = a["lora"]
             if self.lora or not self.fused:
@@ -886,7 +937,9 @@ class LlavaEngine:
                 dgu = ops.gemm_swiglu_bwd(dx, lv["down"], a["gu"], F)
             dh2 = self._lm_linear_bwd(dgu, a["h2"], lv["gu"], gv.get("gu"), i, (("mlp.gate_proj", 0, F), ("mlp.up_proj", F, 2 * F)), sv)
             ops.rmsnorm_bwd(dh2, a["x_mid"], lv["ln2"], a["rstd2"], dx=dx, dx_add=True, dw=gv.get("ln2"), dw_accumulate=acc)
-            dattn = self._lm_linear_bwd(dx, a["attn"], lv["o"], gv.get("o"), i, (("self_attn.o_proj", 0, d),), sv)
+            dattn = self._lm_linear_bwd(dx, a.get("attn_sel", a["attn"]), lv["o"], gv.get("o"), i, (("self_attn.o_proj", 0, d),), sv)
+            if "attn_sel" in a:       # last layer on the labelled rows: back to all token rows (zero elsewhere) for the attention backward
+                dattn, dx = ops.gather_rows(back, d, dattn), ops.gather_rows(back, d, dx)
             qkv = a["qkv"]
             dqkv = torch.empty_like(qkv)
             # the rotary embedding's adjoint runs in the dQ / dK epilogues: dqkv = gradient of the un-rotated q|k|v projection

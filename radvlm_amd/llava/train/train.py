@@ -552,6 +552,10 @@ def train(attn_implementation=None, argv=None, tokenizer=None):
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local),
                                              timeout=datetime.timedelta(weeks=int(os.environ.get("RV_PG_TIMEOUT_WEEKS", 52))))
         pg = torch.distributed.group.WORLD
+    if rank == 0 and str(getattr(training_args, "report_to", "none")).lower() not in ("none", "[]", ""):
+        # the recipe passes --report_to wandb (finetune_radio_7b.sh:83); there is no wandb (and no network) here
+        print(f"[train] --report_to {training_args.report_to}: no experiment tracker is attached; the per-step record (loss, learning_rate, "
+              "grad_norm, epoch, step_time_s, data_wait_s) is printed by rank 0 and kept in trainer_state.json", flush=True)
     parts = tunable_parts(model_args)
     known = {"mm_mlp_adapter", "mm_language_model", "mm_vision_tower"}
     if "mm_vision_resampler" in parts:

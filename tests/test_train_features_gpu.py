@@ -481,3 +481,45 @@ def test_inputs_embeds_and_label_free_call_forms(golden_dir):
     want, valid2 = torch.from_numpy(g["logits"]), torch.from_numpy(g["splice_attention_mask"]).bool()
     assert want.shape == o2.logits.shape
     assert float((o2.logits.cpu() - want)[valid2].abs().max() / want[valid2].abs().max()) < 1.5e-2       # the reference's own logits, valid rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("packed,kw", [(False, {}), (True, {}), (False, {"lora": dict(r=8, alpha=16, dropout=0.0)})])
+def test_head_on_labelled_rows_gives_the_same_loss_and_gradients(golden_dir, packed, kw):
+    """The final norm, lm_head and cross entropy run on the rows that carry a label (ignore_index rows contribute exact zeros to the loss and
+    to every gradient, modeling_llama.py:1326-1337; nothing after the last decoder layer mixes rows).  Against head_rows="all": same loss,
+    same gradients up to the fp32 grouping of the weight-gradient sums, same fp32 logits for callers that ask for them."""
+    _need_gpu()
+    from radvlm_amd.engine import LlavaEngine
+    g, images = _toy_batch(golden_dir)
+    res = {}
+    for mode in ("all", "labeled", "labeled_head_only"):
+        eng = LlavaEngine(GEOMETRIES["toy"], device="cuda:0", init="portable", seed=0, packed=packed, **kw)
+        if kw:      # adapters: lora_B starts at zero -- give it values so that every adapter gradient is exercised
+            gb = torch.Generator().manual_seed(5)
+            for n in eng.lm.names():
+                if n.endswith("lora_B.weight"):
+                    eng.lm.view(n).copy_((torch.randn(eng.lm.shapes[n], generator=gb) * 0.05).to(torch.bfloat16))
+        eng.head_rows = "all" if mode == "all" else "labeled"
+        eng.last_layer_rows = "all" if mode == "labeled_head_only" else "labeled"
+        loss = float(eng.forward(g["input_ids"], g["attention_mask"], g["labels"], images))
+        used, last_sel = eng.ctx["head_idx"], eng.ctx["last_sel"]
+        n_mlp_rows = eng.ctx["layers"][-1]["act"].shape[0]
+        eng.backward()
+        torch.cuda.synchronize()
+        eng.forward(g["input_ids"], g["attention_mask"], g["labels"], images, want_logits=True)      # callers' logits: every row, fp32
+        res[mode] = (loss, eng.last_logits.clone(), eng.grads.float().clone(), used, eng, last_sel, n_mlp_rows)
+        eng.ctx = None
+    M = res["all"][6]
+    assert res["all"][3] is None and res["labeled"][3] is not None and len(res["labeled"][3]) % 64 == 0
+    # the last decoder layer's o_proj / norm / MLP ran on the labelled rows too (same dead-row argument one step earlier)
+    assert res["labeled"][5] and not res["labeled_head_only"][5] and res["labeled"][6] == len(res["labeled"][3]) < M == res["labeled_head_only"][6]
+    n_lab = int((np.roll(g["labels"], -1, 1)[:, :-1] != -100).sum())
+    assert (res["labeled"][3] >= 0).sum() <= n_lab           # the spliced labels: text positions only (image rows carry none)
+    eng = res["all"][4]
+    for mode in ("labeled", "labeled_head_only"):
+        assert abs(res["all"][0] - res[mode][0]) < 1e-6, mode
+        assert torch.equal(res["all"][1], res[mode][1])                                   # callers' fp32 logits: the full product either way
+        for n in eng.lm.names():
+            a, b = eng.lm.view(n, res["all"][2]), eng.lm.view(n, res[mode][2])
+            assert float((a - b).norm()) <= 2e-3 * float(a.norm()) + 1e-12, (mode, n)
