@@ -601,8 +601,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dq_nat_kernel(AttnParams 
             sfor<8>([&](auto bit) {
                 constexpr int bi = decltype(bit)::value;
                 if constexpr (bi + 1 < 8) issue(std::integral_constant<int, (bi + 1) % 8>{}, kq[(bi + 1) & 1], vq[(bi + 1) & 1]);
-                if (bi + 1 < 8) { lds_wait<2, 4>(kq[bi & 1]); lds_wait<2, 4>(vq[bi & 1]); }
-                else { lds_wait<2, 0>(kq[bi & 1]); lds_wait<2, 0>(vq[bi & 1]); }
+                if (bi + 1 < 8) lds_wait4<4>(kq[bi & 1][0], kq[bi & 1][1], vq[bi & 1][0], vq[bi & 1][1]);
+                else lds_wait4<0>(kq[bi & 1][0], kq[bi & 1][1], vq[bi & 1][0], vq[bi & 1][1]);
                 __builtin_amdgcn_sched_barrier(0);
                 constexpr int kb = bi >> 1, ks0 = (bi & 1) * 2;
 #pragma unroll
@@ -769,13 +769,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_nat_kernel(AttnParams
                         rdrow_imm<TILE + (2 * qp + decltype(qq)::value) * 4096>(da[decltype(qq)::value][decltype(ks)::value], ad.row[decltype(ks)::value]);
                     });
                 });
-                lds_wait<KS, 2 * KS>(qa[0]); lds_wait<KS, 2 * KS>(da[0]);       // the 8 reads of the second 16-query block stay in flight
+                lds_wait8<2 * KS>(qa[0], da[0]);       // the 8 reads of the second 16-query block stay in flight
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) { s[0] = mfma16(qa[0][ks], kf[ks], s[0]); dp[0] = mfma16(da[0][ks], vf[ks], dp[0]); }
                 __builtin_amdgcn_sched_barrier(0);
                 issue_c(std::integral_constant<int, 0>{}, dc[0], qc[0]);        // 16 column reads, consumed after the elementwise part
-                lds_wait<KS, 15>(qa[1]); lds_wait<KS, 15>(da[1]);
+                lds_wait8<15>(qa[1], da[1]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks) { s[1] = mfma16(qa[1][ks], kf[ks], s[1]); dp[1] = mfma16(da[1][ks], vf[ks], dp[1]); }
@@ -801,8 +801,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_dkv_nat_kernel(AttnParams
                 const bf16x8 pf = pack8(s[0], s[1]), dsf = pack8(dp[0], dp[1]);
                 sfor<2>([&](auto bit) {
                     constexpr int bi = decltype(bit)::value;
-                    if constexpr (bi == 0) { issue_c(std::integral_constant<int, 1>{}, dc[1], qc[1]); tf_wait4<15>(dc[0]); tf_wait4<15>(qc[0]); }
-                    else { tf_wait4<0>(dc[1]); tf_wait4<0>(qc[1]); }
+                    if constexpr (bi == 0) { issue_c(std::integral_constant<int, 1>{}, dc[1], qc[1]); tf_wait8<15>(dc[0], qc[0]); }
+                    else tf_wait8<0>(dc[1], qc[1]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {

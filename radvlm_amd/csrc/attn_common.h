@@ -133,6 +133,14 @@ DEVINL bf16x8 tf_get(const TFrag& f) {
     const s16x8n r = {f.t0[0], f.t0[1], f.t0[2], f.t0[3], f.t1[0], f.t1[1], f.t1[2], f.t1[3]};
     return __builtin_bit_cast(bf16x8, r);
 }
+// one wait for two batches that were issued together (two s_waitcnt with the same count are one instruction too many per batch)
+template <int LEFT> DEVINL void lds_wait8(bf16x8 (&a)[4], bf16x8 (&b)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "i"(LEFT) : "memory");
+}
+template <int LEFT> DEVINL void tf_wait8(TFrag (&f)[4], TFrag (&h)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%16)" : "+v"(f[0].t0), "+v"(f[0].t1), "+v"(f[1].t0), "+v"(f[1].t1), "+v"(f[2].t0), "+v"(f[2].t1), "+v"(f[3].t0), "+v"(f[3].t1),
+                   "+v"(h[0].t0), "+v"(h[0].t1), "+v"(h[1].t0), "+v"(h[1].t1), "+v"(h[2].t0), "+v"(h[2].t1), "+v"(h[3].t0), "+v"(h[3].t1) : "i"(LEFT) : "memory");
+}
 template <int LEFT> DEVINL void tf_wait4(TFrag (&f)[4]) {
     asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(f[0].t0), "+v"(f[0].t1), "+v"(f[1].t0), "+v"(f[1].t1), "+v"(f[2].t0), "+v"(f[2].t1), "+v"(f[3].t0), "+v"(f[3].t1)
                  : "i"(LEFT) : "memory");

@@ -8,8 +8,11 @@ OUT=../libradvlm_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I. -I../../include -Wno-unused-result -Rpass-analysis=kernel-resource-usage"
 mkdir -p build
 pids=()
+# attention.hip: no SLP vectorisation -- hipcc packs adjacent fp32 adds / multiplies of the softmax and dS arithmetic into v_pk_*_f32, which is slower
+# than the two scalar instructions beside MFMAs (guide: "an anti-lever beside MFMAs"; same-box A/B profiles/r04_ab_attn_no_slp_merged_waits.txt)
 for f in gemm_bf16 attention attention_w64 ops; do
-  ( hipcc $FLAGS -c $f.hip -o build/$f.o 2> build/$f.res || { cat build/$f.res >&2; exit 1; } ) &
+  EXTRA=""; [ $f = attention ] && EXTRA="-fno-slp-vectorize"
+  ( hipcc $FLAGS $EXTRA -c $f.hip -o build/$f.o 2> build/$f.res || { cat build/$f.res >&2; exit 1; } ) &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done

@@ -7,7 +7,10 @@ OUT=$1; shift
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I. -I../../include -Wno-unused-result $@"
 ALL="gemm_bf16 attention attention_w64 ops"
 mkdir -p build/var
-for f in ${ONLY:-$ALL}; do hipcc $FLAGS -c $f.hip -o build/var/$f.o & done; wait
+for f in ${ONLY:-$ALL}; do
+  EXTRA=""; [ $f = attention ] && [ -z "${NO_ATTN_FLAGS:-}" ] && EXTRA="-fno-slp-vectorize"       # as build.sh
+  hipcc $FLAGS $EXTRA -c $f.hip -o build/var/$f.o &
+done; wait
 OBJS=""
 for f in $ALL; do
   if [[ " ${ONLY:-$ALL} " == *" $f "* ]]; then OBJS="$OBJS build/var/$f.o"; else OBJS="$OBJS build/$f.o"; fi
