@@ -241,6 +241,13 @@ int rv_gemm_dropout_add_bf16(const void* A, int64_t lda, const void* B, int64_t 
                              float alpha, float p, uint64_t seed, int accumulate, const void* zeros16, void* stream);
 int rv_lora_down_bf16(const void* X, int64_t ldx, const void* A, int64_t lda, void* T, int64_t ldt, int M, int R, int K, float alpha,
                       float p, uint64_t seed, const void* zeros16, void* stream);
+/* gA[R, K] (+)= 1 / (1 - p) * dT[M, R]^T mask_p(X)[M, K]: the gradient of a LoRA adapter's A matrix (the adjoint of lora_A(lora_dropout(x)),
+ * reference wiring train/train.py:1515-1532) with the forward's dropout mask -- that of rv_dropout_bf16(X as M * K contiguous elements, p, seed) --
+ * re-created in registers: X is read once and dropout(X) never reaches HBM.  dT is the (alpha / r)-scaled gradient of the adapter's inner
+ * activation.  R <= 64, R % 8 == 0, K % 8 == 0, 16-byte aligned X and dT; p > 0 needs ldx == K.  accumulate != 0: added to gA.  workspace: fp32
+ * scratch for the token-slice partial sums, at least R * K * 4 bytes (deterministic reduction: no atomics). */
+int rv_lora_a_grad_bf16(const void* dT, int64_t ldt, const void* X, int64_t ldx, void* gA, int64_t ldg, int M, int R, int K, float p, uint64_t seed,
+                        int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 /* torch.nn.GELU (erf) of the mm_projector (multimodal_projector/builder.py:44) and its derivative. */
 int rv_gelu_fwd(const void* x, void* y, int64_t n, void* stream);
 int rv_gelu_bwd(const void* dy, const void* x, void* dx, int64_t n, void* stream);

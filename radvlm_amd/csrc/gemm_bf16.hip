@@ -1065,6 +1065,114 @@ __global__ void splitk_reduce_kernel(GemmParams P) {
     else ((bf16*)P.C)[(long)m * P.ldc + n] = f2bf(s);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LoRA A-gradient with the adapter's input dropout re-created in registers:
+//     gA[R, K] (+)= 1 / (1 - p) * dT[M, R]^T * mask_p(X)[M, K]       (adjoint of lora_A(lora_dropout(x)), train/train.py:1515-1532)
+// The unfused sequence wrote dropout(X) to HBM (read + write of X) and read it back in a split-K GEMM whose 256-row tile holds 64 useful rows:
+// three passes over X per adapted module, 24 ms of the 13B LoRA step in the dropout kernel alone (profiles/r03c_lora_kernel_ms_per_step.json).
+// Here X is read ONCE: a block owns 128 columns of X and a slice of the token range; per 64-token step every thread loads four 16-byte chunks
+// of X and two of dT, masks X with the SAME counter-based mask the forward used (rv_keep8: element index m * K + k; the 1 / (1 - p) scale rides
+// the reduce kernel's alpha, as it rides alpha in rv_lora_down_bf16), writes both to LDS contraction-major and the four waves read them back
+// transposed (ds_read_b64_tr_b16) as MFMA operands.  The mask hashes (2 per chunk) and HBM bound it, not the MFMAs (16 per wave and step).
+// Partial sums over the token slices go to the workspace in the layout splitk_reduce_kernel finishes (deterministic: no atomics, the replicas
+// of a data-parallel job stay bit-identical).
+constexpr int AG_BM = 64, AG_BN = 128;
+constexpr int AG_XB = AG_BM * AG_BN * 2, AG_TB = AG_BM * 64 * 2, AG_STAGE = AG_XB + AG_TB;      // 16 KiB + 8 KiB per stage, two stages
+struct LoraAGradParams {
+    const bf16* X; const bf16* T; float* ws;
+    long ldx, ldt;
+    int M, R, K, splits;
+    unsigned thr; unsigned long long seed;
+};
+// 128-byte rows ([64 tokens][64 adapter rows]): bank slot of a 32-byte granule = 4 (m & 1) + granule; the 8 rows a 32-lane half of a transposed
+// read touches (m = 8 g + q, g < 2, q < 4) get 8 different slots when the granule is XORed with ((m >> 1) & 1) | ((m >> 3) & 1) << 1
+DEVINL int sw128(int m) { return (((m >> 1) & 1) | (((m >> 3) & 1) << 1)) << 1; }
+DEVINL bf16x8 tr_read16(const char* a, const char* b) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)b);
+    const s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+__global__ __launch_bounds__(256, 3) void lora_agrad_kernel(LoraAGradParams P) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * AG_STAGE];
+    const int wid = wave_id(), lane = lane_id(), tid = (int)threadIdx.x;
+    const int ncb = (P.K + AG_BN - 1) / AG_BN;
+    const int cb = (int)blockIdx.x % ncb, split = (int)blockIdx.x / ncb;      // the column blocks of one token slice run side by side: they share dT in L2
+    const int c0 = cb * AG_BN;
+    const int nst = (P.M + AG_BM - 1) / AG_BM;
+    const int s0 = (int)((long)split * nst / P.splits), s1 = (int)((long)(split + 1) * nst / P.splits);
+    const int xr = tid >> 4, xc = tid & 15;     // X chunks of this thread: token rows xr + 16 i (i < 4), 16-byte chunk xc of the block's 128 columns
+    const int tr = tid >> 3, tc = tid & 7;      // dT chunks: token rows tr + 32 i (i < 2), chunk tc of the (up to) 64 adapter rows
+    const bool xok = c0 + xc * 8 < P.K, tok = tc * 8 < P.R;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 xv0, xv1, xv2, xv3, tv0, tv1;
+    auto ldx8 = [&](int m) __attribute__((always_inline)) { return (xok && m < P.M) ? *(const bf16x8*)(P.X + (long)m * P.ldx + c0 + xc * 8) : zero8; };
+    auto ldt8 = [&](int m) __attribute__((always_inline)) { return (tok && m < P.M) ? *(const bf16x8*)(P.T + (long)m * P.ldt + tc * 8) : zero8; };
+    auto load = [&](int s) __attribute__((always_inline)) {
+        const int m0 = s * AG_BM;
+        xv0 = ldx8(m0 + xr); xv1 = ldx8(m0 + xr + 16); xv2 = ldx8(m0 + xr + 32); xv3 = ldx8(m0 + xr + 48);
+        tv0 = ldt8(m0 + tr); tv1 = ldt8(m0 + tr + 32);
+    };
+    auto put_x = [&](bf16x8 v, int m0, int row, char* st) __attribute__((always_inline)) {
+        if (P.thr) {
+            const unsigned keep = rv_keep8(P.seed, (unsigned long long)(m0 + row) * (unsigned long long)P.K + (unsigned long long)(c0 + xc * 8), P.thr);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (keep >> j) & 1 ? v[j] : (bf16)0.f;
+        }
+        *(bf16x8*)(st + row * 256 + ((xc ^ tswz(row)) << 4)) = v;
+    };
+    auto store = [&](int s, char* st) __attribute__((always_inline)) {
+        const int m0 = s * AG_BM;
+        put_x(xv0, m0, xr, st); put_x(xv1, m0, xr + 16, st); put_x(xv2, m0, xr + 32, st); put_x(xv3, m0, xr + 48, st);
+        *(bf16x8*)(st + AG_XB + tr * 128 + ((tc ^ sw128(tr)) << 4)) = tv0;
+        *(bf16x8*)(st + AG_XB + (tr + 32) * 128 + ((tc ^ sw128(tr + 32)) << 4)) = tv1;
+    };
+    // transposed reads: lane (g, q, p) supplies the address of 4 consecutive features at token row 8 g + q (+ 4 for the second read, + 32 per k-step)
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int mrow = 8 * g + q;
+    int xoff[2], toff[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) xoff[j] = mrow * 256 + (((((wid * 32 + 16 * j) >> 3) + (pp >> 1)) ^ tswz(mrow)) << 4) + (pp & 1) * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) toff[i] = AG_XB + mrow * 128 + ((((16 * i) >> 3) + (pp >> 1)) ^ sw128(mrow)) * 16 + (pp & 1) * 8;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (s0 < s1) { load(s0); store(s0, smem); }
+    __syncthreads();
+    for (int s = s0; s < s1; ++s) {
+        const char* cur = smem + ((s - s0) & 1) * AG_STAGE;
+        char* nxt = smem + (((s - s0) & 1) ^ 1) * AG_STAGE;
+        if (s + 1 < s1) load(s + 1);              // in flight behind this step's MFMAs
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 b[2], a[4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = tr_read16(cur + xoff[j] + kk * 8192, cur + xoff[j] + kk * 8192 + 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = tr_read16(cur + toff[i] + kk * 4096, cur + toff[i] + kk * 4096 + 512);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+        }
+        if (s + 1 < s1) store(s + 1, nxt);        // the other stage: its readers passed the barrier that ended step s - 1
+        __syncthreads();
+    }
+    // lane holds D[adapter row 16 i + 4 g + r][column c0 + 32 wid + 16 j + (lane & 15)]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ar = 16 * i + 4 * g + r, col = c0 + wid * 32 + 16 * j + (lane & 15);
+                if (ar < P.R && col < P.K) P.ws[((long)split * P.R + ar) * P.K + col] = acc[i][j][r];
+            }
+}
+
 // Finishes MODE 3: for every tail tile, C = act(alpha * sum_slices partial + bias) + residual (8 columns per thread).
 __global__ __launch_bounds__(256) void tail_reduce_kernel(GemmParams P) {
     const int nwg = P.tiles_m * P.tiles_n;
@@ -1415,6 +1523,34 @@ extern "C" int rv_gemm_swiglu_bwd_bf16(const void* dY, int64_t ldy, const void* 
     P.lda = ldy; P.ldb = ldw; P.ldc = lddgu; P.M = M; P.N = F; P.K = K; P.alpha = 1.f;
     P.F = F; P.G = (const bf16*)GU; P.ldg = ldgu;
     return launch_fused<EPI_SWIGLU_BWD, true>(P, (M + BM2 - 1) / BM2, (F + BN2 - 1) / BN2, (hipStream_t)stream);
+}
+
+// gA[R, K] (+)= 1 / (1 - p) * dT[M, R]^T mask_p(X)[M, K] with the mask of rv_dropout_bf16(X viewed as M * K contiguous elements, p, seed): the
+// gradient of a LoRA adapter's A matrix in ONE pass over X (lora_agrad_kernel above).  R <= 64, R % 8 == 0, K % 8 == 0; with p > 0 X must be
+// contiguous (ldx == K).  workspace: fp32 scratch for the token-slice partial sums (>= R * K * 4 bytes; more slices fit in a larger one).
+extern "C" int rv_lora_a_grad_bf16(const void* dT, int64_t ldt, const void* X, int64_t ldx, void* gA, int64_t ldg, int M, int R, int K, float p,
+                                   uint64_t seed, int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!dT || !X || !gA || !workspace || M <= 0 || R <= 0 || K <= 0 || p < 0.f || p >= 1.f) return RV_ERR_ARG;
+    if (R > 64 || (R & 7) || (K & 7) || (ldx & 7) || (ldt & 7) || (p > 0.f && ldx != K)) return RV_ERR_ARG;
+    if ((((uintptr_t)X) | ((uintptr_t)dT)) & 15) return RV_ERR_ARG;
+    const int ncb = (K + AG_BN - 1) / AG_BN, nst = (M + AG_BM - 1) / AG_BM;
+    int splits = (3 * cu_budget() + ncb - 1) / ncb;          // three blocks per CU are resident (48 KiB of LDS each)
+    if (splits > nst) splits = nst;
+    if (splits > 32) splits = 32;
+    const int64_t per = (int64_t)R * K * 4;
+    if (splits > workspace_bytes / per) splits = (int)(workspace_bytes / per);
+    if (splits < 1) return RV_ERR_ARG;
+    LoraAGradParams Q;
+    Q.X = (const bf16*)X; Q.T = (const bf16*)dT; Q.ws = (float*)workspace; Q.ldx = ldx; Q.ldt = ldt; Q.M = M; Q.R = R; Q.K = K; Q.splits = splits;
+    Q.thr = rv_dropout_thr16(p); Q.seed = seed;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(lora_agrad_kernel, dim3((unsigned)(ncb * splits)), dim3(256), 0, st, Q);
+    GemmParams P{};
+    P.M = R; P.N = K; P.splits = splits; P.ws = (float*)workspace; P.alpha = p > 0.f ? 1.f / (1.f - p) : 1.f; P.bias = nullptr; P.act = RV_ACT_NONE;
+    P.R = accumulate ? gA : nullptr; P.ldr = ldg; P.res_f32 = 0; P.C = gA; P.ldc = ldg; P.out_f32 = 0;
+    const long total = (long)R * K;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, P);
+    return rv_check_launch();
 }
 
 // T[M, R] = alpha / (1 - p) * dropout_p(X)[M, K] A[R, K]^T with the mask of rv_dropout_bf16(X viewed as M * K contiguous elements, p, seed):

@@ -883,7 +883,7 @@ class LlavaEngine:
                 dx = torch.empty(x.shape[0], w.shape[1], dtype=BF16, device=self.device)
             if self.lora_p > 0:
                 seed = self._lora_seed(i, lname)
-                ops.gemm(dts, ops.dropout(x, self.lora_p, seed), ta=True, tb=True, out=gA, residual=gA if acc else None, workspace=ws)
+                ops.lora_a_grad(dts, x, gA, self.lora_p, seed, acc, ws)     # gA (+)= dts^T dropout(x): the mask is re-created in registers
                 if not base_done:
                     ops.gemm(dyj, w[c0:c1], tb=True, out=dx, residual=None if first else dx)
                 ops.gemm_dropout_add(dts, A, dx, self.lora_p, seed)   # dx += dropout'(dts A): the mask is applied in the GEMM epilogue

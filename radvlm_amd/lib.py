@@ -36,6 +36,7 @@ _SIGS = {
     "rv_dropout_add_bf16": [_c_void_p, _c_void_p, _i64, _f32, ctypes.c_uint64, _c_void_p],
     "rv_gemm_dropout_add_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _i32, _i32, _i32, _f32, _f32, ctypes.c_uint64, _i32, _c_void_p,
                                  _c_void_p],
+    "rv_lora_a_grad_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _i32, _i32, _f32, ctypes.c_uint64, _i32, _c_void_p, _i64, _c_void_p],
     "rv_lora_down_bf16": [_c_void_p, _i64, _c_void_p, _i64, _c_void_p, _i64, _i32, _i32, _i32, _f32, _f32, ctypes.c_uint64, _c_void_p, _c_void_p],
     "rv_transpose_bf16": [_c_void_p, _i64, _i64, _i64, _c_void_p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _c_void_p],
     "rv_rmsnorm_fwd": [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _i32, _i32, _f32, _c_void_p],

@@ -382,6 +382,20 @@ def lora_down(x, a, alpha, p, seed, out=None):
     return out
 
 
+def lora_a_grad(dt, x, ga, p, seed, accumulate, workspace):
+    """ga[r, K] (+)= dt[M, r]^T @ dropout(x, p, seed)[M, K] in one pass over x, the mask re-created in registers (rv_lora_a_grad_bf16: x contiguous,
+    r <= 64, r % 8 == 0, K % 8 == 0); other shapes take the two-launch sequence (dropout kernel, split-K weight-gradient GEMM)."""
+    M, K = x.shape
+    r = dt.shape[1]
+    ok = (x.is_contiguous() and dt.stride(1) == 1 and dt.stride(0) % 8 == 0 and ga.stride(1) == 1 and r <= 64 and r % 8 == 0 and K % 8 == 0
+          and x.data_ptr() % 16 == 0 and dt.data_ptr() % 16 == 0 and workspace is not None and workspace.numel() * workspace.element_size() >= r * K * 4)
+    if not ok:
+        return gemm(dt, dropout(x.contiguous(), p, seed) if p > 0 else x, ta=True, tb=True, out=ga, residual=ga if accumulate else None, workspace=workspace)
+    lib.call("rv_lora_a_grad_bf16", dt, dt.stride(0), x, x.stride(0), ga, ga.stride(0), M, r, K, float(p), int(seed), int(bool(accumulate)),
+             workspace, workspace.numel() * workspace.element_size())
+    return ga
+
+
 def gemm_dropout_add(a, b, y, p, seed, tb=True, alpha=1.0, accumulate=True):
     """y (+)= dropout(alpha * a @ op(b)) with the mask of dropout(., p, seed) over y's elements, applied in the GEMM epilogue (the product is
     never stored unmasked).  a [M, K], b [K, N] (tb) or [N, K]; y [M, N] contiguous rows."""

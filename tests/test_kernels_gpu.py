@@ -751,6 +751,37 @@ def test_lora_down_projection_with_dropout_inside(ops, M, K, R, p):
     assert relerr(ops.lora_down(wide[:, :K], a, alpha, p, seed).float().cpu(), want.cpu()) < TOL
 
 
+@pytest.mark.parametrize("M,K,R,p", [(200, 128, 64, 0.25), (64, 64, 8, 0.5), (4099, 5120, 64, 0.05), (1000, 1384, 16, 0.1), (129, 136, 8, 0.0), (22528, 512, 64, 0.05)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_lora_a_gradient_with_the_dropout_mask_recreated_in_registers(ops, M, K, R, p, accumulate):
+    """rv_lora_a_grad_bf16: gA (+)= dT^T dropout_p(x) in one pass over x -- against the two-launch sequence it replaces (rv_dropout_bf16, then the
+    split-K weight-gradient GEMM) and, through an identity dT, element by element against the mask of rv_dropout_bf16 (the forward's mask: peft
+    LoraLayer semantics, reference train/train.py:1515-1532).  Ragged token counts, column counts that are not a multiple of the 128-column block,
+    fewer than 64 adapter rows."""
+    x, dt = rnd(330, (M, K), 1.0).cuda(), rnd(331, (M, R), 0.5).cuda()
+    g0 = rnd(332, (R, K), 3.0).cuda()
+    seed = 777
+    ws = torch.empty(8 << 20, dtype=torch.float32, device="cuda")
+    xd = ops.dropout(x, p, seed) if p > 0 else x
+    want = dt.float().T @ xd.float() + (g0.float() if accumulate else 0)
+    got = ops.lora_a_grad(dt, x, g0.clone(), p, seed, accumulate, ws)
+    # the unfused operand is bf16(x / (1 - p)); the one-pass kernel scales the fp32 sum instead: the two differ by that rounding (2^-9 per element)
+    assert got.shape == (R, K) and relerr(got.float().cpu(), want.cpu()) < TOL
+    again = ops.lora_a_grad(dt, x, g0.clone(), p, seed, accumulate, ws)
+    assert torch.equal(got, again)                                           # deterministic (no atomics): replicas stay bit-identical
+    if M == 64 and R == 8:
+        sel = torch.zeros(M, R, dtype=torch.bfloat16, device="cuda")
+        for r in range(R):
+            sel[r * 5, r] = 1.0                                                # row r of gA = the masked token row 5 r of x
+        rows = ops.lora_a_grad(sel, x, torch.empty(R, K, dtype=torch.bfloat16, device="cuda"), p, seed, False, ws)
+        pick = xd[[r * 5 for r in range(R)]]
+        assert torch.equal(rows != 0, pick != 0)
+        assert relerr(rows.float().cpu(), pick.float().cpu()) < TOL
+    # a workspace too small for one partial sum, or non-contiguous x, takes the two-launch sequence
+    small = torch.empty(16, dtype=torch.float32, device="cuda")
+    assert relerr(ops.lora_a_grad(dt, x, g0.clone(), p, seed, accumulate, small if R * K * 4 > 64 else None).float().cpu(), want.cpu()) < TOL
+
+
 @pytest.mark.parametrize("M,N,K,p", [(300, 256, 64, 0.25), (1000, 5120, 64, 0.05), (256, 512, 128, 0.5), (64, 72, 64, 0.1)])
 def test_gemm_with_dropout_in_the_epilogue(ops, M, N, K, p):
     """rv_gemm_dropout_add_bf16: y += dropout(dt @ A) with the mask applied to the accumulators (the adapter branch of a LoRA layer's input

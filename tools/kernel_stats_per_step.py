@@ -14,7 +14,7 @@ FAMILIES = [("gemm_kernel_256", "GEMM 256x256 (all forms)"), ("gemm_nt_kernel", 
             ("splitk_reduce", "GEMM split-K reduce"), ("attn_fwd_nat", "attention fwd (hd 128)"), ("attn_bwd_dq_nat", "attention bwd dQ"),
             ("attn_bwd_dkv_nat", "attention bwd dK/dV"), ("attn_fwd_kernel", "tower attention fwd (hd 64)"), ("attn_bwd_", "tower attention bwd"),
             ("adamw", "AdamW"), ("rmsnorm", "RMSNorm fwd+bwd"), ("layernorm", "LayerNorm"), ("colsum", "column sums"), ("sumsq", "grad norm"),
-            ("cross_entropy", "cross entropy"), ("lora_down", "LoRA down-projection (dropout inside)"), ("dropout", "dropout (LoRA)"), ("swiglu", "SwiGLU (unfused)"), ("rope", "RoPE (unfused)"),
+            ("cross_entropy", "cross entropy"), ("lora_down", "LoRA down-projection (dropout inside)"), ("lora_agrad", "LoRA A-gradient (mask re-created in registers)"), ("dropout", "dropout (LoRA)"), ("swiglu", "SwiGLU (unfused)"), ("rope", "RoPE (unfused)"),
             ("group_sum_heads", "GQA group sum")]
 STARTUP = ("distribution_elementwise", "bfloat16_copy", "cast_bf16_f32", "copyBuffer", "FillFunctor<float>")
 
