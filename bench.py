@@ -82,15 +82,17 @@ def cpu_baseline(geo, seconds_budget=25.0):
     g = torch.Generator().manual_seed(0)
     P = {}
     pre = "model.layers.0."
-    for n, shp in (("self_attn.q_proj.weight", (d, d)), ("self_attn.k_proj.weight", (d, d)), ("self_attn.v_proj.weight", (d, d)),
+    kvh = l.get("kv_heads", l["heads"])
+    kvd = d // l["heads"] * kvh             # grouped-query attention (Qwen2): k / v projections are kv_heads * head_dim wide
+    for n, shp in (("self_attn.q_proj.weight", (d, d)), ("self_attn.k_proj.weight", (kvd, d)), ("self_attn.v_proj.weight", (kvd, d)),
                    ("self_attn.o_proj.weight", (d, d)), ("mlp.gate_proj.weight", (l["ffn"], d)), ("mlp.up_proj.weight", (l["ffn"], d)),
                    ("mlp.down_proj.weight", (d, l["ffn"])), ("input_layernorm.weight", (d,)), ("post_attention_layernorm.weight", (d,))):
         P[pre + n] = (torch.randn(*shp, generator=g) * 0.02).requires_grad_(True)
     x = torch.randn(1, S, d, generator=g).requires_grad_(True)
-    cos, sin = O.rope_cos_sin(S, d // l["heads"])
+    cos, sin = O.rope_cos_sin(S, d // l["heads"], l.get("rope_theta", 1e4))
 
     def dec():
-        y = O.decoder_layer(x, P, pre, l["heads"], [S], cos, sin)
+        y = O.decoder_layer(x, P, pre, l["heads"], [S], cos, sin, eps=l.get("rms_eps", 1e-5), kv_heads=kvh)
         y.sum().backward()
 
     def timeit(fn, reps):
@@ -108,7 +110,10 @@ def cpu_baseline(geo, seconds_budget=25.0):
     PV = {k: torch.randn(*shp, generator=g) * 0.02 for k, shp in O.param_shapes(geo1).items() if k.startswith(vp)}
     pix = torch.randn(1, 3, v["image"], v["image"], generator=g)
     with torch.no_grad():
-        t_vit = timeit(lambda: O.clip_vision_hidden(PV, geo1, pix, -2), 40)  # embeddings + 1 layer
+        if v.get("kind") == "siglip":
+            t_vit = timeit(lambda: O.siglip_vision_hidden(PV, geo1, pix), 40)    # embeddings + 1 layer (the loaded tower has layers - 1)
+        else:
+            t_vit = timeit(lambda: O.clip_vision_hidden(PV, geo1, pix, -2), 40)  # embeddings + 1 layer
     # head
     wh = (torch.randn(l["vocab"], d, generator=g) * 0.02).requires_grad_(True)
     hN = torch.randn(1, S, d, generator=g).requires_grad_(True)

@@ -162,3 +162,18 @@ def test_save_total_limit_keeps_the_newest_checkpoints(tmp_path):
     assert sorted(os.listdir(tmp_path)) == ["checkpoint-100", "checkpoint-20", "checkpoint-final"]
     tr.args.save_total_limit = None
     assert tr._rotate_checkpoints(str(tmp_path), rank=0) == []
+
+
+@pytest.mark.parametrize("geometry", ["toy", "toy_qwen"])
+def test_bench_cpu_baseline_runs_on_both_model_families(geometry):
+    """bench.py's `cpu_baseline` leg (the oracle timed on the host cores) on a CLIP + Llama geometry and on a SigLIP + Qwen2 one (grouped-query
+    k / v widths, rope theta, the SigLIP tower): the non-headline workloads' bench lines carry it too."""
+    import copy
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("rv_bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from radvlm_amd.config import GEOMETRIES
+    out = bench.cpu_baseline(copy.deepcopy(GEOMETRIES[geometry]))
+    assert out["kind"] == "port" and out["unit"] == "pairs/s" and out["value"] > 0 and out["cores"] >= 1
