@@ -514,14 +514,15 @@ def lora_linear(x, W, A, B, scale, p, seed, rnd, bias=None, residual=None):
 
 def lora_linear_backward(dy, x, W, A, B, t, scale, p, seed, rnd):
     """Backward of `lora_linear` as LlavaEngine._lora_linear_bwd stores it: dts = rnd(scale * dy B) (r-wide), gB = dy^T t and
-    gA = dts^T dropout(x) (fp32 sums; dropout(x) = rnd(keep * x / (1 - p)) is a stored tensor there), the base input gradient
-    rnd(dy W) and the adapter branch added through the masked epilogue: dx = rnd(dx_base + keep * (dts A) / (1 - p))."""
+    gA = dts^T (keep * x) / (1 - p) (fp32 sums; since round 4 the masked x is an operand re-created in registers, not a stored
+    tensor -- rv_lora_a_grad_bf16 -- so it is not rounded and the 1 / (1 - p) scales the sum, as in the forward; peft materialises
+    dropout(x) in bf16, a rounding of <= 2^-9 per term), the base input gradient rnd(dy W) and the adapter branch added through
+    the masked epilogue: dx = rnd(dx_base + keep * (dts A) / (1 - p))."""
     flat = lambda u: u.reshape(-1, u.shape[-1])
     keep = dropout_keep_mask(x.shape, p, seed).to(x.dtype) if p > 0 else torch.ones_like(x)
     dts = rnd(F.linear(dy, B.t()) * scale)
     gB = flat(dy).t().double().matmul(flat(t).double()).float()
-    xd = rnd(x * keep / (1.0 - p)) if p > 0 else x
-    gA = flat(dts).t().double().matmul(flat(xd).double()).float()
+    gA = (flat(dts).t().double().matmul(flat(x * keep).double()) / ((1.0 - p) if p > 0 else 1.0)).float()
     if p > 0:
         dx = rnd(rnd(F.linear(dy, W.t())) + keep * F.linear(dts, A.t()) / (1.0 - p))
     else:

@@ -340,8 +340,12 @@ def test_lora_kernels_against_the_emulation_with_the_same_mask(pdrop):
     G.bf("d(t) = scale dy B (skinny one-pass kernel)", ops.lora_down(dy_d, ops.transpose(B_d), scale, 0.0, 0), Rb["dts"])
     dts_d = dev(Rb["dts"])
     G.f32("wgrad lora_B", ops.gemm(dy_d, t_d, ta=True, tb=True, out_dtype=F32), Rb["gB"])
-    xd_d = ops.dropout(x_d, pdrop, seed) if pdrop > 0 else x_d
-    G.f32("wgrad lora_A", ops.gemm(dts_d, xd_d, ta=True, tb=True, out_dtype=F32), Rb["gA"])
+    if pdrop > 0:      # the product path: one pass over x, the forward's mask re-created in registers, fp32 token-slice sums, one bf16 store
+        ws = torch.empty(8 << 20, dtype=F32, device=DEV)
+        g_a = ops.lora_a_grad(dts_d, x_d, torch.empty(r, K, dtype=torch.bfloat16, device=DEV), pdrop, seed, False, ws)
+        G.bf("rv_lora_a_grad_bf16: wgrad lora_A, mask re-created in registers", g_a, rnd(Rb["gA"]))
+    else:
+        G.f32("wgrad lora_A", ops.gemm(dts_d, x_d, ta=True, tb=True, out_dtype=F32), Rb["gA"])
     if pdrop > 0:
         dx = ops.gemm(dy_d, W_d, tb=True)
         ops.gemm_dropout_add(dts_d, A_d, dx, pdrop, seed)
