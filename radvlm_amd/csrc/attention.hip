@@ -235,24 +235,39 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
     constexpr int HD = 128, KS = 4, DB = 8, TILE = 64 * 256, STAGE = 2 * TILE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wid = wave_id(), lane = lane_id(), g = lane >> 4, c = lane & 15;
-    int qblk, h, b;
-    block_coords<CAUSAL>(qblk, h, b);
+    // CAUSAL: a block owns the query-block PAIR (nq - 1 - xb, xb) of its (sample, head): every pair costs the same 2 nq + 2 key tiles (no long /
+    // short blocks, no tail round: S = 704, b = 32, 32 heads is exactly 6 rounds of 512 resident blocks), and the second block's Q rows and first
+    // K / V tile are fetched behind the first block's last tile, so half of the exposed prologues disappear (S = 704: a prologue was a third of a
+    // block's life).  Non-causal: one query block per block, as before.
+    int xb, h, b;
+    block_coords<false>(xb, h, b);
     const long rb = P.cu ? (long)P.cu[b] : (long)b * P.S;
-    const int S = P.cu ? P.cu[b + 1] - P.cu[b] : P.S, q0 = qblk * 128 + wid * 32;
-    if (qblk * 128 >= S) return;
+    const int S = P.cu ? P.cu[b + 1] - P.cu[b] : P.S;
+    const int nq = (S + 127) >> 7;
+    const bool paired = CAUSAL && P.paired;
+    if ((paired ? 2 * xb : xb) >= nq) return;
+    int qblk = CAUSAL ? nq - 1 - xb : xb;          // unpaired causal: the long blocks first
+    const int npass = (paired && qblk != xb) ? 2 : 1;
+    int q0 = qblk * 128 + wid * 32;
     const int len = (P.lens && !P.cu) ? P.lens[b] : S;
     const float sl2 = P.scale * LOG2E;
 
-    bf16x8 qf[2][KS];
+    bf16x8 qf[2][KS], qn[2][KS];
+    auto load_q = [&](bf16x8 (&dst)[2][KS], int q0_) __attribute__((always_inline)) {
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
-        const int row = min(q0 + qs * 16 + c, S - 1);
-        const bf16* p = P.q + (rb + row) * P.ld_q + h * HD + g * 8;
+        for (int qs = 0; qs < 2; ++qs) {
+            const int row = min(q0_ + qs * 16 + c, S - 1);
+            const bf16* p = P.q + (rb + row) * P.ld_q + h * HD + g * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[qs][ks] = *(const bf16x8*)(p + ks * 32);
-    }
-    const int kv_end = CAUSAL ? min(len, qblk * 128 + 128) : len;
-    const int ntiles = (kv_end + 63) >> 6;
+            for (int ks = 0; ks < KS; ++ks) dst[qs][ks] = *(const bf16x8*)(p + ks * 32);
+        }
+    };
+    load_q(qf, q0);
+    int kv_end = CAUSAL ? min(len, qblk * 128 + 128) : len;
+    int ntiles = (kv_end + 63) >> 6;
+    int toff = 0;                 // tiles run before this pass: LDS stage parity and the read-address toggle continue across the seam
+    bool more = npass > 1;        // another query block follows this one
+    bool landed = false;          // this block's first K / V tile and Q rows are known to have landed (wave-uniform)
     const int hk = h / P.nrep;
     // staging: buffer resources over this sample's rows (rows >= S read as zero), loop-invariant lane offsets, scalar tile offset
     const __amdgpu_buffer_rsrc_t rsK = rows_rsrc(P.k + rb * P.ld_k, S, P.ld_k), rsV = rows_rsrc(P.v + rb * P.ld_v, S, P.ld_v);
@@ -285,18 +300,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
     auto tile = [&](int t, auto interior_tag) {
         constexpr bool INTERIOR = decltype(interior_tag)::value;
         ATT_T0();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the pair's second block waited before the first block's epilogue stores)
+        landed = false;
         __syncthreads();
         ATT_ACC(0);
         ad.shift((t & 1) ? STAGE : -STAGE);
         // interior tiles issue the next tile's staging pieces (8 per wave, 60-100 issue cycles each) behind this tile's score MFMAs (K) and
         // softmax (V) instead of in front of its first fragment read: +2 % (same-box A/B)
         char* nx = smem + ((t + 1) & 1) * STAGE;
-        const int kv0 = t * 64;
+        const int u = t - toff;           // key tile of this query block
+        const int kv0 = u * 64;
         constexpr bool LATE = INTERIOR;
-        if (!LATE && (INTERIOR || t + 1 < ntiles)) {
-            plK.stage(rsK, (t + 1) * kstep + hoff, nx, wid);
-            plV.stage(rsV, (t + 1) * vstep + hoff, nx + TILE, wid);
+        if (!LATE) {
+            if (u + 1 < ntiles) {
+                plK.stage(rsK, (u + 1) * kstep + hoff, nx, wid);
+                plV.stage(rsV, (u + 1) * vstep + hoff, nx + TILE, wid);
+            } else if (more) {            // last tile of the pair's first block: the second block's first K / V tile and Q rows
+                plK.stage(rsK, hoff, nx, wid);
+                plV.stage(rsV, hoff, nx + TILE, wid);
+                load_q(qn, xb * 128 + wid * 32);
+            }
         }
         if (!INTERIOR && CAUSAL && kv0 > q0 + 31) return;  // every key of this tile is in the future of this wave's rows
 
@@ -338,10 +361,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
         issue_v(std::integral_constant<int, 1>{}, vq[1]);
 #ifdef RV_ATTN_STAMPS
         { asm volatile("" ::: "memory"); const long long a_ = __builtin_readcyclecounter();
-          if (LATE) plK.stage(rsK, (t + 1) * kstep + hoff, nx, wid);
+          if (LATE) plK.stage(rsK, (u + 1) * kstep + hoff, nx, wid);
           asm volatile("" ::: "memory"); att_dma += __builtin_readcyclecounter() - a_; }
 #else
-        if (LATE) plK.stage(rsK, (t + 1) * kstep + hoff, nx, wid);
+        if (LATE) plK.stage(rsK, (u + 1) * kstep + hoff, nx, wid);
 #endif
         // lane holds S^T[key = kv0 + 16kb + 4g + r][q = q0 + 16qs + c]
         const bool edge = !INTERIOR && ((kv0 + 64 > len) || (CAUSAL && kv0 + 63 > q0));     // wave-uniform
@@ -440,10 +463,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
         }
 #ifdef RV_ATTN_STAMPS
         { asm volatile("" ::: "memory"); const long long a_ = __builtin_readcyclecounter();
-          if (LATE) plV.stage(rsV, (t + 1) * vstep + hoff, nx + TILE, wid);
+          if (LATE) plV.stage(rsV, (u + 1) * vstep + hoff, nx + TILE, wid);
           asm volatile("" ::: "memory"); att_dma += __builtin_readcyclecounter() - a_; }
 #else
-        if (LATE) plV.stage(rsV, (t + 1) * vstep + hoff, nx + TILE, wid);
+        if (LATE) plV.stage(rsV, (u + 1) * vstep + hoff, nx + TILE, wid);
 #endif
         ATT_ACC(2);
         // O^T[d][q] += V^T[d][key] P^T[key][q]
@@ -475,26 +498,47 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
         att_dbg[4] += 1;
 #endif
     };
-    // interior tiles: below the block's first query row (causal) and wholly inside the sample; never the last tile
-    const int n_int = min(CAUSAL ? min(qblk * 2, len >> 6) : (len >> 6), ntiles - 1);
-    int t = 0;
-    for (; t < n_int; ++t) tile(t, std::true_type{});
-    for (; t < ntiles; ++t) tile(t, std::false_type{});
+    for (int pass = 0;; ++pass) {
+        // interior tiles: below the block's first query row (causal) and wholly inside the sample; never the last tile
+        const int n_int = min(CAUSAL ? min(qblk * 2, len >> 6) : (len >> 6), ntiles - 1);
+        int t = toff;
+        for (; t < toff + n_int; ++t) tile(t, std::true_type{});
+        for (; t < toff + ntiles; ++t) tile(t, std::false_type{});
+        // the second block's first tile and Q rows were issued a whole key tile ago: retire them HERE, so that its first tile does not wait for
+        // the output stores below (vmcnt counts them too)
+        if (more) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); landed = true; }
 #pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
-        float lt = l[qs];
-        lt += __shfl_xor(lt, 16, 64);
-        lt += __shfl_xor(lt, 32, 64);
-        const int qidx = q0 + qs * 16 + c;
-        if (qidx >= S) continue;
-        const float inv = 1.f / lt;
-        bf16* op = P.out + (rb + qidx) * P.ld_o + h * HD + 4 * g;
+        for (int qs = 0; qs < 2; ++qs) {
+            float lt = l[qs];
+            lt += __shfl_xor(lt, 16, 64);
+            lt += __shfl_xor(lt, 32, 64);
+            const int qidx = q0 + qs * 16 + c;
+            if (qidx >= S) continue;
+            const float inv = 1.f / lt;
+            bf16* op = P.out + (rb + qidx) * P.ld_o + h * HD + 4 * g;
 #pragma unroll
-        for (int db = 0; db < DB; ++db) {
-            const f32x4 v = o[qs][db] * inv;
-            *(bf16x4*)(op + db * 16) = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            for (int db = 0; db < DB; ++db) {
+                const f32x4 v = o[qs][db] * inv;
+                *(bf16x4*)(op + db * 16) = bf16x4{f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+            }
+            if (g == 0 && P.lse) P.lse[(long)(b * P.H + h) * P.S_pad + qidx] = (m[qs] + __builtin_amdgcn_logf(lt)) * LN2;
         }
-        if (g == 0 && P.lse) P.lse[(long)(b * P.H + h) * P.S_pad + qidx] = (m[qs] + __builtin_amdgcn_logf(lt)) * LN2;
+        if (!more) break;
+        // the pair's second (short) query block: its Q rows and first K / V tile are already in flight
+        more = false;
+        toff += ntiles;
+        qblk = xb;
+        q0 = qblk * 128 + wid * 32;
+        kv_end = min(len, qblk * 128 + 128);
+        ntiles = (kv_end + 63) >> 6;
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+            m[qs] = -INFINITY; l[qs] = 0.f; thr[qs] = -INFINITY;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) qf[qs][ks] = qn[qs][ks];
+#pragma unroll
+            for (int db = 0; db < DB; ++db) o[qs][db] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
 #ifdef RV_ATTN_STAMPS
     if (P.delta && lane == 0) {
@@ -504,6 +548,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_nat_kernel(AttnParams P) {
         const long blk = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
         long long* o_ = (long long*)P.delta + (blk * 4 + wid) * 6;
         for (int i = 0; i < 6; ++i) o_[i] = att_dbg[i];
+        if (wid == 0) {   // where and when the block ran: [start, end, HW_ID | XCC_ID << 32] behind the per-wave records
+            const long nblk = (long)gridDim.x * gridDim.y * gridDim.z;
+            long long* w_ = (long long*)P.delta + nblk * 4 * 6 + blk * 3;
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            w_[0] = att_start; w_[1] = att_start + att_dbg[5]; w_[2] = (long long)hw | ((long long)xcc << 32);
+        }
     }
 #endif
 }
@@ -1208,6 +1258,16 @@ int rv_attn_fwd_w64_launch(const AttnParams& P, int causal, hipStream_t st);
 // 0 = default (the two-waves-per-SIMD kernels of this file: faster on every shape measured, profiles/r04_ab_attn_w64_*), 1 = the same,
 // explicitly, 2 = the one-wave-per-SIMD forward of attention_w64.hip.
 static int g_attn_family = 0;
+// compute units of the current device (one process drives one GPU: read once)
+static int g_attn_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;
+    }
+    return cus;
+}
 extern "C" int rv_attn_select_kernel(int which) {
     if (which < 0 || which > 2) return RV_ERR_ARG;
     g_attn_family = which;
@@ -1232,7 +1292,14 @@ extern "C" int rv_attn_fwd_nat(const void* q, int64_t ld_q, const void* k, int64
     P.delta = g_attn_stamp;
 #endif
     if (g_attn_family == 2) return rv_attn_fwd_w64_launch(P, causal, (hipStream_t)stream);
-    dim3 grid((S + 127) / 128, H, B);
+    // causal: one block per PAIR of query blocks (attn_fwd_nat_kernel) -- all blocks then cost the same, so the pairing is only taken when the last
+    // round of resident blocks (2 per CU) is nearly full; otherwise single query blocks, the long ones first, pack the CUs better
+    const int nq = (S + 127) / 128;
+    const long pairs = (long)((nq + 1) / 2) * H * B;
+    const long slots = 2L * g_attn_cus();
+    const long rounds = (pairs + slots - 1) / slots;
+    P.paired = causal && nq >= 2 && (double)(rounds * slots - pairs) <= 0.06 * (double)(rounds * slots);
+    dim3 grid(P.paired ? (nq + 1) / 2 : nq, H, B);
     const int smem = 2 * 2 * 64 * 256;
     if (causal) { set_smem(attn_fwd_nat_kernel<true>, smem); hipLaunchKernelGGL(attn_fwd_nat_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, P); }
     else { set_smem(attn_fwd_nat_kernel<false>, smem); hipLaunchKernelGGL(attn_fwd_nat_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, P); }

@@ -22,6 +22,7 @@ struct AttnParams {
     // backward only: adjoint of the rotary embedding applied to dQ / dK in the epilogue (q, k are stored rotated; the projection
     // weights see un-rotated gradients).  cs = fp32 [positions, HD/2, 2]; position of row r of sample b: rope_pos[rb + r] or r.
     const float* rope_cs; const int* rope_pos;
+    int paired;       // forward, causal: a block runs the query-block pair (nq - 1 - x, x) instead of one query block (attn_fwd_nat_kernel)
     int rope_dk;      // the dK/dV pass rotates dK itself (0 when per-query-head partials are summed first: group_sum_heads_kernel rotates)
 };
 

@@ -30,8 +30,12 @@ for B, H, Hkv, S in ((32, 32, 32, 704), (8, 32, 32, 3056), (2, 28, 4, 7499)):
     for _ in range(3):
         run()
     l.rv_debug_set_attn_stamp_buffer(buf.data_ptr())
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     run()
+    e1.record()
     torch.cuda.synchronize()
+    wall_us = e0.elapsed_time(e1) * 1e3
     l.rv_debug_set_attn_stamp_buffer(None)
     raw = buf.cpu().numpy().reshape(nblk, 4, 6)
     dma = (raw[:, :, 4] >> 20).astype(np.float64)
@@ -44,6 +48,10 @@ for B, H, Hkv, S in ((32, 32, 32, 704), (8, 32, 32, 3056), (2, 28, 4, 7499)):
     names = ["wait + barrier", "K reads + score MFMAs", "softmax", "P V MFMAs"]
     print(f"B={B} H={H}:{Hkv} S={S}: {tiles / a.shape[0] / 4:.1f} tiles per wave, {tot / tiles:.0f} cycles per wave-tile (incl. prologue / epilogue "
           f"{100 * (1 - a[:, :, :4].sum() / tot):.1f} % of the wave's life)")
+    life = a[:, :, 5].max(1)                          # a block lives as long as its slowest wave
+    slots = 2 * 256
+    print(f"    blocks that ran {a.shape[0]}, mean block life {life.mean():.0f} cycles; sum of block lives / {slots} resident slots = {life.sum() / slots:.0f} cycles "
+          f"= {life.sum() / slots / 2.1e3:.0f} us at 2.1 GHz; the launch took {wall_us:.0f} us (stamped build)")
     for i, n in enumerate(names):
         print(f"    {n:24s} {a[:, :, i].sum() / tiles:7.0f} cycles per wave-tile  ({100 * a[:, :, i].sum() / tot:5.1f} %)")
     print(f"    of the softmax phase: issuing the next tile's 8 LDS-DMA pieces {dma.sum() / tiles:7.0f} cycles per wave-tile ({100 * dma.sum() / tot:5.1f} %)")
