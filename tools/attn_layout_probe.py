@@ -24,11 +24,13 @@ def timeit(fn, n=10):
 for B, H, S in ((32, 32, 704), (8, 32, 3056)):
     s_pad = (S + 63) // 64 * 64
     res = {}
-    for name, (b_, h_) in (("token-major [rows, 3 * H * 128]", (B, H)), ("head-major  [(b, h), S, 128]   ", (B * H, 1))):
+    cases = [("token-major [rows, 3 * H * 128]", (B, H), 0), ("token-major, q / k / v apart    ", (B, H), -1), ("head-major  [(b, h), S, 128]   ", (B * H, 1), -1)]
+    cases += [(f"token-major, row stride + {pad:4d} el", (B, H), pad) for pad in (64, 128, 256, 512, 1024, 2048)]
+    for name, (b_, h_), pad in cases:
         d = h_ * hd
-        if h_ == H:
-            qkv = torch.randn(b_ * S, 3 * d, device="cuda", dtype=torch.bfloat16)
-            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+        if pad >= 0:
+            qkv = torch.randn(b_ * S, 3 * d + pad, device="cuda", dtype=torch.bfloat16)
+            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:3 * d]
         else:
             q, k, v = (torch.randn(b_ * S, d, device="cuda", dtype=torch.bfloat16) for _ in range(3))
         dout = torch.randn(b_ * S, d, device="cuda", dtype=torch.bfloat16)
