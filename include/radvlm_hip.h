@@ -182,6 +182,8 @@ int rv_attn_fwd_nat(const void* q, int64_t ld_q, const void* k, int64_t ld_k, co
  * 64 query rows per wave, hand-placed softmax (attention_w64.hip; measured slower, kept for the A/B record).  Same results up to the
  * rounding of the running maximum's granularity (64- vs 32-key steps). */
 int rv_attn_select_kernel(int which);
+/* 1 when rv_attn_fwd_nat runs a causal [B, H, S] batch as query-block pairs on the current device, 0 for single query blocks (test hook). */
+int rv_attn_fwd_nat_pairs(int B, int H, int S, int causal);
 int rv_attn_bwd_gqa(const void* q, int64_t ld_q, const void* k, int64_t ld_k, const void* v, int64_t ld_v, const void* o,
                     int64_t ld_o, const void* dout, int64_t ld_do, const void* qT, const void* kT, const void* doT,
                     const float* lse, float* delta, void* dq, int64_t ld_dq, void* dk, int64_t ld_dk, void* dv,

@@ -1274,6 +1274,18 @@ extern "C" int rv_attn_select_kernel(int which) {
     return RV_OK;
 }
 
+// Causal forward: one block per PAIR of query blocks (attn_fwd_nat_kernel) -- all blocks then cost the same, so the pairing is only taken when the
+// last round of resident blocks (2 per CU) is nearly full; otherwise single query blocks, the long ones first, pack the CUs better.
+static int attn_fwd_pairs(int B, int H, int S, int causal) {
+    const int nq = (S + 127) / 128;
+    const long pairs = (long)((nq + 1) / 2) * H * B;
+    const long slots = 2L * g_attn_cus();
+    const long rounds = (pairs + slots - 1) / slots;
+    return causal && nq >= 2 && (double)(rounds * slots - pairs) <= 0.06 * (double)(rounds * slots);
+}
+// which of the two forms rv_attn_fwd_nat takes for a shape on this device (1 = pairs): lets a test assert that it covers both
+extern "C" int rv_attn_fwd_nat_pairs(int B, int H, int S, int causal) { return attn_fwd_pairs(B, H, S, causal); }
+
 #if defined(RV_ATTN_STAMPS) || defined(RV_W64_STAMPS)
 static float* g_attn_stamp = nullptr;
 extern "C" int rv_debug_set_attn_stamp_buffer(void* p) { g_attn_stamp = (float*)p; return 0; }
@@ -1292,13 +1304,8 @@ extern "C" int rv_attn_fwd_nat(const void* q, int64_t ld_q, const void* k, int64
     P.delta = g_attn_stamp;
 #endif
     if (g_attn_family == 2) return rv_attn_fwd_w64_launch(P, causal, (hipStream_t)stream);
-    // causal: one block per PAIR of query blocks (attn_fwd_nat_kernel) -- all blocks then cost the same, so the pairing is only taken when the last
-    // round of resident blocks (2 per CU) is nearly full; otherwise single query blocks, the long ones first, pack the CUs better
     const int nq = (S + 127) / 128;
-    const long pairs = (long)((nq + 1) / 2) * H * B;
-    const long slots = 2L * g_attn_cus();
-    const long rounds = (pairs + slots - 1) / slots;
-    P.paired = causal && nq >= 2 && (double)(rounds * slots - pairs) <= 0.06 * (double)(rounds * slots);
+    P.paired = attn_fwd_pairs(B, H, S, causal);
     dim3 grid(P.paired ? (nq + 1) / 2 : nq, H, B);
     const int smem = 2 * 2 * 64 * 256;
     if (causal) { set_smem(attn_fwd_nat_kernel<true>, smem); hipLaunchKernelGGL(attn_fwd_nat_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, P); }

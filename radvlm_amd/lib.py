@@ -96,7 +96,7 @@ _SIGS = {
     "rv_add_bf16": [_c_void_p, _c_void_p, _c_void_p, _i64, _c_void_p],
 }
 
-EXPORTED_SYMBOLS = ["rv_version", "rv_gemm_select_kernel", "rv_gemm_set_cu_budget", "rv_attn_select_kernel"] + sorted(_SIGS)
+EXPORTED_SYMBOLS = ["rv_version", "rv_gemm_select_kernel", "rv_gemm_set_cu_budget", "rv_attn_select_kernel", "rv_attn_fwd_nat_pairs"] + sorted(_SIGS)
 
 _lib = None
 

@@ -222,6 +222,44 @@ def test_attention_fwd_bwd(ops, B, S, H, hd, causal, lens):
             assert float(gg.view(B, S, H, hd).transpose(1, 2).cpu().float()[~vm].abs().max()) == 0.0, name
 
 
+@pytest.mark.parametrize("B,H,Hkv,S,ragged", [(8, 32, 32, 500, False), (8, 32, 8, 1000, True), (16, 32, 32, 300, False)])
+def test_attention_forward_query_block_pairs_are_bit_identical_to_single_blocks(ops, B, H, Hkv, S, ragged):
+    """The causal natural-layout forward runs query blocks in PAIRS (nq - 1 - x, x) when the pairs fill the CUs' resident slots (attention.hip,
+    rv_attn_fwd_nat): a batch large enough to take that path must give, bit for bit, what its samples give when they are sent two at a time (too few
+    blocks for pairs: one query block per block, the path every small test takes) -- odd and even numbers of query blocks, grouped-query heads,
+    ragged lengths; plus the torch reference on one head."""
+    hd = 128
+    d, kvd = H * hd, Hkv * hd
+    s_pad = (S + 63) // 64 * 64
+    qkv = rnd(41, (B * S, d + 2 * kvd), 1.0).cuda()
+    q, k, v = qkv[:, :d], qkv[:, d:d + kvd], qkv[:, d + kvd:]
+    lens = [S - (37 * b) % (S // 2) for b in range(B)] if ragged else None
+    lens_t = torch.tensor(lens, dtype=torch.int32, device="cuda") if ragged else None
+    from radvlm_amd import lib as L_
+    plan = L_.load().rv_attn_fwd_nat_pairs
+    assert plan(B, H, S, 1) == 1 and plan(2, H, S, 1) == 0 and plan(B, H, S, 0) == 0       # the two calls below do take the two forms
+    out, lse = ops.attn_fwd(q, k, None, B, S, H, hd, s_pad, True, lens=lens_t, kv_heads=Hkv, v=v)
+    for b0 in range(0, B, 2):
+        rows = slice(b0 * S, (b0 + 2) * S)
+        o2, l2 = ops.attn_fwd(q[rows], k[rows], None, 2, S, H, hd, s_pad, True, lens=None if lens_t is None else lens_t[b0:b0 + 2], kv_heads=Hkv, v=v[rows])
+        valid = torch.ones(2, S, dtype=torch.bool, device="cuda")
+        if ragged:
+            for i in range(2):
+                valid[i, lens[b0 + i]:] = False
+        assert torch.equal(out[rows][valid.view(-1)], o2[valid.view(-1)]), b0
+        assert torch.equal(lse[b0:b0 + 2, :, :S][valid[:, None, :].expand(2, H, S)], l2[:, :, :S][valid[:, None, :].expand(2, H, S)]), b0
+    # one (sample, head) against torch
+    b, h = B - 1, H - 1
+    L = lens[b] if ragged else S
+    qf = q[b * S:b * S + L, h * hd:(h + 1) * hd].float()
+    kf = k[b * S:b * S + L, (h // (H // Hkv)) * hd:(h // (H // Hkv) + 1) * hd].float()
+    vf = v[b * S:b * S + L, (h // (H // Hkv)) * hd:(h // (H // Hkv) + 1) * hd].float()
+    sc = (qf @ kf.T) / math.sqrt(hd)
+    sc = sc.masked_fill(torch.triu(torch.ones(L, L, dtype=torch.bool, device="cuda"), 1), float("-inf"))
+    ref = torch.softmax(sc, -1) @ vf
+    assert relerr(out[b * S:b * S + L, h * hd:(h + 1) * hd].float(), ref) < TOL
+
+
 @pytest.mark.parametrize("B,S,H,Hkv,hd,lens", [(2, 200, 4, 2, 64, [200, 77]), (1, 300, 8, 2, 128, None), (2, 70, 6, 1, 128, [70, 33])])
 def test_attention_gqa(ops, B, S, H, Hkv, hd, lens):
     """Grouped-query attention (Qwen2): query head h reads k/v head h // (H/Hkv); dK/dV sum over the group (repeat_kv adjoint)."""
