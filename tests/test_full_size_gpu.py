@@ -34,7 +34,13 @@ GRAD_REL_L2 = 0.22            # per tensor ||g_hip - g_fp32||_2 / ||g_fp32||_2: 
                               # (q/k projections of layer 30) -- the bf16 noise of a 32-layer random-init model, whose logits the
                               # bf16-EMULATING oracle itself misses by 5.7 % (emu_vs_fp32_l2); kernel errors proper are gated per op in
                               # tests/test_backward_parity_gpu.py
-GRAD_NORM_REL = 5e-3          # global gradient norm (measured 8e-4, 1.2e-3)
+GRAD_NORM_REL = 5e-3          # global gradient norm, step 1 (measured 9e-5 on the 7B model, 1.05e-3 on the recipe model)
+GRAD_NORM_REL_STEP2 = 1e-2    # step 2: the two models have taken one AdamW step each (first step ~ lr * sign(g): gradient elements inside the bf16
+                              # noise take opposite signs).  Measured: 1.4e-3 (7B); recipe model 3.2e-3 with the head on every row and 5.3e-3 with the
+                              # head on the labelled rows -- two equally valid bf16 realisations of the SAME kernels (the run with round 3's kernel
+                              # library gives the same digits; the gathered-row lm_head GEMMs differ from the all-row ones in 2e-5 .. 1.4e-3 of their
+                              # output elements by one ulp, tools/probe/headrows_probe.py).  Round 3's single 5e-3 gate sat inside that spread:
+                              # profiles/r04_full_size_parity_qwen2_siglip.json.  Kernel errors proper are gated per op.
 UPDATE_MEAN = 0.21            # mean |master_hip - master_fp32| / lr per tensor after two steps (an AdamW update is <= ~1 lr per step; a slice
                               # that was zeroed, skipped or updated with a wrong gradient reads ~1 .. 1e3 here); measured worst 0.164 (layer 31 k_proj)
 UPDATE_FRAC_BAD = 0.09        # fraction of a tensor's elements whose two-step update differs by more than 0.5 lr (measured worst 0.071)
@@ -94,6 +100,8 @@ def test_config2_full_size_forward_backward_two_adamw_steps(layers):
     lr, wd, clip, b1, b2, eps = 2e-5, 0.05, 1.0, 0.9, 0.999, 1e-8      # the recipe's learning rate (finetune_radio_7b.sh)
 
     eng = LlavaEngine(geo, device="cuda:0", init="fast", seed=11)
+    if os.environ.get("RV_FULLSIZE_HEAD_ROWS") == "all":     # A/B of round 4's head-on-the-labelled-rows (the default): every row through the head
+        eng.head_rows = eng.last_layer_rows = "all"
     names = eng.lm.names()
     n_params = sum(eng.lm.offsets[n][1] for n in names)
     if layers == full_layers:
@@ -146,7 +154,7 @@ def test_config2_full_size_forward_backward_two_adamw_steps(layers):
         gn_h, gn_r = math.sqrt(sq_h), math.sqrt(sq_r)
         rec[tag] = dict(worst_rel_l2=worst, worst_tensor=worst_name, per_kind_worst_rel_l2=per_kind, grad_norm_hip=gn_h, grad_norm_fp32=gn_r)
         dump()
-        assert abs(gn_h - gn_r) <= GRAD_NORM_REL * gn_r, (tag, gn_h, gn_r)
+        assert abs(gn_h - gn_r) <= (GRAD_NORM_REL_STEP2 if tag.endswith("step2") else GRAD_NORM_REL) * gn_r, (tag, gn_h, gn_r)
         return gn_r
 
     M, Vv, MASTER = {}, {}, {}
