@@ -357,6 +357,27 @@ def main():
     pairs = args.batch * world * args.steps
     value = pairs / dt
 
+    # the same step with NOTHING restricted to the labelled rows (every row through the last layer's MLP, the final norm, lm_head and the cross
+    # entropy: the reference's own evaluation order), timed beside the headline number on the same box: `config.every_row_variant`
+    every_row = None
+    if args.head_rows == "labeled":
+        eng.head_rows = eng.last_layer_rows = "all"
+        for _ in range(max(2, args.warmup)):
+            step()
+        fence()
+        t1 = time.perf_counter()
+        n_alt = args.steps
+        for _ in range(n_alt):
+            step()
+        fence()
+        dt_alt = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt_alt], device=f"cuda:{local}")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt_alt = float(t[0])
+        every_row = {"pairs_per_s": args.batch * world * n_alt / dt_alt, "ms_per_step": dt_alt / n_alt * 1e3, "steps": n_alt}
+        eng.head_rows = eng.last_layer_rows = "labeled"
+
     # exposed communication: time the compute stream spends waiting for the last gradient buckets (events around finish_grad_sync)
     comm_wait_ms = None
     if eng.sync is not None:
@@ -430,6 +451,7 @@ def main():
                                    f"{args.batch} pairs/GPU/step", "global_batch": args.batch * world,
                        "seq_len": {"anyres": 3056, "radvlm": 7499}.get(args.workload, s_cxr),
                        "parallelism": f"dp{world}", "final_loss": final_loss, "rows_with_a_label_only": {"all": "nothing", "head": "final norm, lm_head, cross entropy", "labeled": "last layer's o_proj / norm / MLP, final norm, lm_head, cross entropy"}[args.head_rows],
+                       **({"every_row_variant": every_row} if every_row else {}),
                        **({"text_lens": args.text_lens, "packed": args.packed} if args.text_lens else {})},
             "roofline": roofline,
             "distributed": {"world": world, "ranks_seen": ranks_seen, "backend": backend if not rehearsal else f"{backend} (rehearsal: all ranks on one GPU)",
